@@ -1,0 +1,109 @@
+"""Numeric contract of the engine: every simulation / task constant in one place.
+
+Values and where they come from in the reference:
+  dt 0.0083, controlFrequencyInv 4, max_episode_length 300, gravity -9.81
+      RobotLearning/omniisaacgymenvs/cfg/task/QuadrupedPoseControl.yaml:13,18,19,21
+  drive: velocity mode, kp 0, kd 100, max effort 1.5, velocity limit 3.0 (action scale)
+      robot/quadruped_robot.py:42,61-64 ; robot/base/robot.py:252-254,452-454
+  reward / termination constants
+      tasks/quadruped_pose_control_tasks/quadruped_pose_control.py:27-87,127-137
+  vertical deltas
+      tasks/quadruped_pose_control_tasks/quadruped_pose_control_vertical.py:84-87,123-126
+
+Contact parameters (mu, tip_radius, baumgarte, max_depen_vel, pgs_iters) belong to THIS engine's
+contact model; the reference delegates contact to PhysX (TGS, 16+2
+iterations, contact_offset 0.005, max depenetration velocity 100 -- YAML :41-50) whose
+algorithm is not reproducible here.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import List
+
+import numpy as np
+
+MODE_LOCO = 0    # free base on a ground plane
+MODE_MANI = 1    # fixed (inverted) base + free plate
+
+
+def _f(x):
+    return field(default_factory=lambda: list(x))
+
+
+@dataclass
+class EngineParams:
+    # ---- physics
+    dt: float = 0.0083
+    substeps: int = 4
+    pgs_iters: int = 8
+    gravity: float = 9.81
+    kd: float = 100.0
+    tau_max: float = 1.5
+    act_scale: float = 3.0
+    mu: float = 1.0
+    tip_radius: float = 0.002
+    baumgarte: float = 0.2
+    max_depen_vel: float = 1.0
+    mode: int = MODE_LOCO
+    fixed_base_pos: List[float] = _f([0.0, 0.0, 0.0])
+    fixed_base_quat: List[float] = _f([0.0, 1.0, 0.0, 0.0])
+    plate_mass: float = 2.4                              # Design/ObjectURDF/plate.urdf:5-23
+    plate_com: List[float] = _f([0.0, 0.0, 0.004])
+    plate_inertia: List[float] = _f([0.05, 0.05, 0.1])
+    plate_half: List[float] = _f([0.25, 0.25, 0.004])
+    plate_center: List[float] = _f([0.0, 0.0, 0.004])
+    # ---- reset
+    init_q: List[float] = _f([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
+    init_base_pos: List[float] = _f([0.0, 0.0, 0.14])
+    init_base_quat: List[float] = _f([1.0, 0.0, 0.0, 0.0])
+    init_plate_pos: List[float] = _f([0.0, 0.0, 0.14])
+    init_plate_quat: List[float] = _f([0.0, 1.0, 0.0, 0.0])
+    default_tip: List[float] = _f([-0.0937, 0.1223, -0.1774, 0.0937, 0.1408, -0.1773,
+                                   -0.0937, -0.1408, -0.1773, 0.0937, -0.1223, -0.1774])
+    goal_lo: List[float] = _f([-0.4, -0.4, -1.57])
+    goal_hi: List[float] = _f([0.4, 0.4, 1.57])
+    # ---- observation scales
+    s_pos: float = 5.0
+    s_lin: float = 2.0
+    s_ang: float = 0.25
+    s_q: float = 0.3
+    s_qd: float = 0.3
+    # ---- reward
+    quat_scale: float = 0.5
+    rot_eps: float = 0.1
+    trans_scale: float = -2.5
+    acc_scale: float = -0.0005
+    rate_scale: float = -0.02
+    bonus: float = 600.0
+    limit_pen: float = -5.0
+    fall_pen: float = 0.0
+    succ_thresh: float = 0.15
+    max_consec: int = 15
+    max_episode: int = 300
+    d23_pen: List[float] = _f([0.43, 2.53])
+    d23_rst: List[float] = _f([0.384, 2.61])
+    # dof1 windows per limb a1..a4: a1,a4 [min,max]; a2,a3 mirrored (quadruped_pose_control.py:482-501)
+    d1_pen: List[List[float]] = field(default_factory=lambda: [[-2.35, 0.78], [-0.78, 2.35], [-0.78, 2.35], [-2.35, 0.78]])
+    d1_rst: List[List[float]] = field(default_factory=lambda: [[-2.44, 0.87], [-0.87, 2.44], [-0.87, 2.44], [-2.44, 0.87]])
+    h_base: float = 0.05
+    h_corner: float = 0.01
+    h_knee: float = 0.04
+    corner: List[List[float]] = field(default_factory=lambda: [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04],
+                                                               [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]])
+    # ---- bookkeeping
+    max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
+
+    @property
+    def ctrl_dt(self) -> float:
+        return self.dt * self.substeps
+
+
+def loco_params(**kw) -> EngineParams:
+    """Horizontal locomotion task (QuadrupedPoseControl)."""
+    return replace(EngineParams(), **kw)
+
+
+def mani_params(**kw) -> EngineParams:
+    """Horizontal manipulation task (QuadrupedManipulatePlate): fixed inverted base at the origin,
+    plate dropped from z = 0.14 (quadruped_manipulate_plate.py:91-94,150-151)."""
+    return replace(EngineParams(mode=MODE_MANI), **kw)

@@ -1,0 +1,483 @@
+/*
+ * lm_oracle.c -- CPU oracle (see lm_oracle.h for scope, citations and the
+ * "parity unpinned vs PhysX" statement).  TEST INFRASTRUCTURE ONLY.
+ *
+ * Physics algorithm (deliberately NOT the kernel's algorithm):
+ *   dense world-axes body Jacobians -> M = sum J^T I J, h = sum J^T (I a_vp + w x I w, m(a_vp+g))
+ *   -> loop closure by coordinate projection G (20 tree DoF -> 12 independent)
+ *   -> implicit velocity drive as a diagonal augmentation dt*kd, 2-pass torque clamp
+ *   -> dense Cholesky, dense Delassus W = Jc Minv Jc^T, projected Gauss-Seidel
+ *   -> semi-implicit Euler.
+ */
+#include "lm_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define NU 18
+
+/* ------------------------------------------------------------------ small math */
+static void m3mul(const real* A, const real* B, real* C) {
+  real T[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    real s = 0; for (int k = 0; k < 3; k++) s += A[3*i+k] * B[3*k+j]; T[3*i+j] = s; }
+  memcpy(C, T, sizeof(T));
+}
+static void m3T(const real* A, real* C) { real T[9]; for (int i=0;i<3;i++) for(int j=0;j<3;j++) T[3*i+j]=A[3*j+i]; memcpy(C,T,sizeof(T)); }
+static void m3v(const real* A, const real* v, real* o) { real t[3]; for (int i=0;i<3;i++) t[i]=A[3*i]*v[0]+A[3*i+1]*v[1]+A[3*i+2]*v[2]; o[0]=t[0];o[1]=t[1];o[2]=t[2]; }
+static void m3Tv(const real* A, const real* v, real* o) { real t[3]; for (int i=0;i<3;i++) t[i]=A[i]*v[0]+A[3+i]*v[1]+A[6+i]*v[2]; o[0]=t[0];o[1]=t[1];o[2]=t[2]; }
+static void cross(const real* a, const real* b, real* o) { real t0=a[1]*b[2]-a[2]*b[1], t1=a[2]*b[0]-a[0]*b[2], t2=a[0]*b[1]-a[1]*b[0]; o[0]=t0;o[1]=t1;o[2]=t2; }
+static real dot3(const real* a, const real* b) { return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
+
+static void quat_to_mat(const real* q, real* R) { /* wxyz */
+  real w=q[0],x=q[1],y=q[2],z=q[3];
+  R[0]=1-2*(y*y+z*z); R[1]=2*(x*y-w*z);   R[2]=2*(x*z+w*y);
+  R[3]=2*(x*y+w*z);   R[4]=1-2*(x*x+z*z); R[5]=2*(y*z-w*x);
+  R[6]=2*(x*z-w*y);   R[7]=2*(y*z+w*x);   R[8]=1-2*(x*x+y*y);
+}
+static void quat_mul(const real* a, const real* b, real* o) { /* Hamilton, wxyz */
+  real w=a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3];
+  real x=a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2];
+  real y=a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1];
+  real z=a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0];
+  o[0]=w;o[1]=x;o[2]=y;o[3]=z;
+}
+static void quat_conj(const real* a, real* o) { o[0]=a[0]; o[1]=-a[1]; o[2]=-a[2]; o[3]=-a[3]; }
+/* rotation about a unit axis (Rodrigues) */
+static void axis_rot(const real* a, real th, real* R) {
+  real c = cos(th), s = sin(th), v = 1 - c;
+  R[0]=c+a[0]*a[0]*v;      R[1]=a[0]*a[1]*v-a[2]*s; R[2]=a[0]*a[2]*v+a[1]*s;
+  R[3]=a[1]*a[0]*v+a[2]*s; R[4]=c+a[1]*a[1]*v;      R[5]=a[1]*a[2]*v-a[0]*s;
+  R[6]=a[2]*a[0]*v-a[1]*s; R[7]=a[2]*a[1]*v+a[0]*s; R[8]=c+a[2]*a[2]*v;
+}
+
+/* loop-closure function g(D) = 2 atan(sqrt2 tan(D/2)) and derivatives */
+static void closure_g(real D, real* g, real* g1, real* g2) {
+  const real s2 = sqrt((real)2);
+  real den = 3 - cos(D);
+  *g = 2 * atan2(s2 * sin(D / 2), cos(D / 2));
+  *g1 = 2 * s2 / den;
+  *g2 = -2 * s2 * sin(D) / (den * den);
+}
+
+void lmo_quat_from_euler(real roll, real pitch, real yaw, real* q) {
+  real cy=cos(yaw*0.5), sy=sin(yaw*0.5), cr=cos(roll*0.5), sr=sin(roll*0.5), cp=cos(pitch*0.5), sp=sin(pitch*0.5);
+  q[0]=cy*cr*cp+sy*sr*sp; q[1]=cy*sr*cp-sy*cr*sp; q[2]=cy*cr*sp+sy*sr*cp; q[3]=sy*cr*cp-cy*sr*sp;
+}
+
+static uint32_t mix32(uint32_t x) { /* lowbias32 finalizer */
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+void lmo_hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, real* u3) {
+  uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(episode * 0x85EBCA6BU + 0x165667B1U));
+  for (uint32_t k = 0; k < 3; k++) {
+    uint32_t r = mix32(base + (k + 1U) * 0xC2B2AE35U);
+    u3[k] = (real)(r >> 8) * (real)(1.0 / 16777216.0);
+  }
+}
+int lmo_sizeof_real(void) { return (int)sizeof(real); }
+
+/* ------------------------------------------------------------------ kinematics */
+typedef struct {
+  real Rw[LMO_MAXB][9], ow[LMO_MAXB][3], zw[LMO_MAXB][3], cw[LMO_MAXB][3], Iw[LMO_MAXB][9];
+  real qt[LMO_NTREE];               /* tree joint angles */
+  real G[LMO_NTREE][LMO_NQ];        /* d qtree / d q */
+  real qdd_vp[LMO_NTREE];           /* passive joint accel at qdd_indep = 0 */
+  real qdt[LMO_NTREE];              /* tree joint rates */
+} kin_t;
+
+static void kin_compute(const lmo_model* m, const real* R0, const real* p0, const real* q, const real* qd, kin_t* K) {
+  memset(K->G, 0, sizeof(K->G)); memset(K->qdd_vp, 0, sizeof(K->qdd_vp));
+  for (int i = 0; i < LMO_NQ; i++) { K->qt[i] = q[i]; K->G[i][i] = 1; }
+  for (int c = 0; c < m->nclos; c++) {
+    int pd = m->clos_p[c], a = m->clos_a[c], b = m->clos_b[c]; real s = (real)m->clos_s[c];
+    real g, g1, g2; closure_g(q[a] - q[b], &g, &g1, &g2);
+    K->qt[pd] = s * g; K->G[pd][a] = s * g1; K->G[pd][b] = -s * g1;
+    real dd = qd ? (qd[a] - qd[b]) : 0;
+    K->qdd_vp[pd] = s * g2 * dd * dd;
+  }
+  for (int t = 0; t < LMO_NTREE; t++) { real s = 0; if (qd) for (int j = 0; j < LMO_NQ; j++) s += K->G[t][j] * qd[j]; K->qdt[t] = s; }
+  for (int k = 0; k < m->nb; k++) {
+    if (m->parent[k] < 0) { memcpy(K->Rw[k], R0, 9*sizeof(real)); memcpy(K->ow[k], p0, 3*sizeof(real)); }
+    else {
+      int par = m->parent[k]; real Rt[9], ax[3], pt[3], Rj[9], Rq[9], t[3];
+      for (int i = 0; i < 9; i++) Rt[i] = (real)m->Rt[k][i];
+      for (int i = 0; i < 3; i++) { ax[i] = (real)m->axis[k][i]; pt[i] = (real)m->pt[k][i]; }
+      axis_rot(ax, K->qt[m->dof[k]], Rq);
+      m3mul(K->Rw[par], Rt, Rj); m3mul(Rj, Rq, K->Rw[k]);
+      m3v(K->Rw[par], pt, t); for (int i = 0; i < 3; i++) K->ow[k][i] = K->ow[par][i] + t[i];
+      m3v(K->Rw[k], ax, K->zw[k]);
+    }
+    real c[3], Ib[9], T[9], RT[9];
+    for (int i = 0; i < 3; i++) c[i] = (real)m->com[k][i];
+    for (int i = 0; i < 9; i++) Ib[i] = (real)m->inertia[k][i];
+    m3v(K->Rw[k], c, c); for (int i = 0; i < 3; i++) K->cw[k][i] = K->ow[k][i] + c[i];
+    m3mul(K->Rw[k], Ib, T); m3T(K->Rw[k], RT); m3mul(T, RT, K->Iw[k]);
+  }
+}
+
+void lmo_fk(const lmo_model* m, const lmo_params* p, const real* phys, real* tips, real* knees) {
+  real R0[9], p0[3], q0[4]; kin_t K;
+  if (p->mode == 0) { quat_to_mat(phys + 3, R0); memcpy(p0, phys, 3*sizeof(real)); }
+  else { for (int i=0;i<4;i++) q0[i]=(real)p->fixed_base_quat[i]; quat_to_mat(q0, R0); for (int i=0;i<3;i++) p0[i]=(real)p->fixed_base_pos[i]; }
+  kin_compute(m, R0, p0, phys + 13, NULL, &K);
+  for (int i = 0; i < 4; i++) { real off[3], t[3]; for (int j=0;j<3;j++) off[j]=(real)m->tip_off[i][j];
+    m3v(K.Rw[m->tip_body[i]], off, t); for (int j=0;j<3;j++) tips[3*i+j] = K.ow[m->tip_body[i]][j] + t[j]; }
+  for (int i = 0; i < 8; i++) for (int j=0;j<3;j++) knees[3*i+j] = K.ow[m->knee_body[i]][j];
+}
+
+/* ------------------------------------------------------------------ dense dynamics
+ * Generalised velocity u[18]:
+ *   mode 0: [w_b(3), v_b(3)] = base spatial velocity in BASE coordinates, then qd(12)
+ *   mode 1: [w_b(3), v_b(3)] = plate spatial velocity (at plate origin) in PLATE coordinates, then qd(12)
+ */
+typedef struct {
+  real M[NU][NU], h[NU];
+  real tip[4][3];          /* world tip points */
+  real Jt[4][3][NU];       /* world-axes linear Jacobian of tip points wrt u (robot side) */
+  real R0[9], p0[3];       /* robot base pose */
+  real Rf[9], pf[3];       /* free body pose (= base in mode 0, plate in mode 1) */
+} dyn_t;
+
+static void dyn_compute(const lmo_model* m, const lmo_params* p, const real* phys, dyn_t* D) {
+  kin_t K; real wb[3] = {0,0,0}, vb[3] = {0,0,0};
+  const real* q = phys + 13; const real* qd = phys + 25;
+  if (p->mode == 0) {
+    quat_to_mat(phys + 3, D->R0); memcpy(D->p0, phys, 3*sizeof(real));
+    m3Tv(D->R0, phys + 10, wb); m3Tv(D->R0, phys + 7, vb);
+    memcpy(D->Rf, D->R0, sizeof(D->R0)); memcpy(D->pf, D->p0, sizeof(D->p0));
+  } else {
+    real q0[4]; for (int i=0;i<4;i++) q0[i]=(real)p->fixed_base_quat[i]; quat_to_mat(q0, D->R0);
+    for (int i=0;i<3;i++) D->p0[i]=(real)p->fixed_base_pos[i];
+    quat_to_mat(phys + 40, D->Rf); memcpy(D->pf, phys + 37, 3*sizeof(real));
+  }
+  kin_compute(m, D->R0, D->p0, q, qd, &K);
+  memset(D->M, 0, sizeof(D->M)); memset(D->h, 0, sizeof(D->h));
+  const int floating = (p->mode == 0);
+  /* per-body classical velocity-product kinematics */
+  real w[LMO_MAXB][3], al[LMO_MAXB][3], ao[LMO_MAXB][3];
+  for (int k = 0; k < m->nb; k++) {
+    int par = m->parent[k];
+    if (par < 0) {
+      real vo[3]; m3v(D->R0, wb, w[k]); m3v(D->R0, vb, vo);
+      al[k][0]=al[k][1]=al[k][2]=0; cross(w[k], vo, ao[k]);
+    } else {
+      real zq[3], t[3], d[3], t2[3]; real qdk = K.qdt[m->dof[k]];
+      for (int i=0;i<3;i++) { zq[i] = K.zw[k][i]*qdk; w[k][i] = w[par][i] + zq[i]; }
+      cross(w[par], zq, t);
+      for (int i=0;i<3;i++) al[k][i] = al[par][i] + t[i] + K.zw[k][i]*K.qdd_vp[m->dof[k]];
+      for (int i=0;i<3;i++) d[i] = K.ow[k][i]-K.ow[par][i];
+      cross(al[par], d, t); cross(w[par], d, t2); cross(w[par], t2, t2);
+      for (int i=0;i<3;i++) ao[k][i] = ao[par][i] + t[i] + t2[i];
+    }
+  }
+  /* Jacobians + accumulation */
+  for (int k = 0; k < m->nb; k++) {
+    real JA[3][NU], JL[3][NU]; memset(JA,0,sizeof(JA)); memset(JL,0,sizeof(JL));
+    real JAt[3][LMO_NTREE], JLt[3][LMO_NTREE]; memset(JAt,0,sizeof(JAt)); memset(JLt,0,sizeof(JLt));
+    for (int j = k; m->parent[j] >= 0; j = m->parent[j]) {
+      int dj = m->dof[j]; real r[3], t[3];
+      for (int i=0;i<3;i++) r[i] = K.cw[k][i]-K.ow[j][i];
+      cross(K.zw[j], r, t);
+      for (int i=0;i<3;i++) { JAt[i][dj] = K.zw[j][i]; JLt[i][dj] = t[i]; }
+    }
+    for (int i=0;i<3;i++) for (int c=0;c<LMO_NQ;c++) { real sa=0, sl=0;
+      for (int t=0;t<LMO_NTREE;t++) { sa += JAt[i][t]*K.G[t][c]; sl += JLt[i][t]*K.G[t][c]; }
+      JA[i][6+c]=sa; JL[i][6+c]=sl; }
+    if (floating) {
+      real r[3]; for (int i=0;i<3;i++) r[i]=K.cw[k][i]-D->p0[i];
+      for (int c=0;c<3;c++) { real col[3]={D->R0[c],D->R0[3+c],D->R0[6+c]}, t[3]; cross(col, r, t); /* (R e_c) x r = -[r]x R e_c */
+        for (int i=0;i<3;i++) { JA[i][c]=col[i]; JL[i][c]=t[i]; JL[i][3+c]=col[i]; } }
+    }
+    /* forces */
+    real mass=(real)m->mass[k], rc[3], t[3], t2[3], ac[3], Iw_[3], nA[3], fL[3];
+    for (int i=0;i<3;i++) rc[i]=K.cw[k][i]-K.ow[k][i];
+    cross(al[k], rc, t); cross(w[k], rc, t2); cross(w[k], t2, t2);
+    for (int i=0;i<3;i++) ac[i]=ao[k][i]+t[i]+t2[i];
+    m3v(K.Iw[k], w[k], Iw_); cross(w[k], Iw_, t); m3v(K.Iw[k], al[k], nA);
+    for (int i=0;i<3;i++) { nA[i]+=t[i]; fL[i]=mass*ac[i]; } fL[2]+=mass*(real)p->gravity;
+    for (int a=0;a<NU;a++) {
+      real IJ[3]; real ja[3]={JA[0][a],JA[1][a],JA[2][a]}; m3v(K.Iw[k], ja, IJ);
+      for (int b=a;b<NU;b++) { real s=0; for (int i=0;i<3;i++) s += IJ[i]*JA[i][b] + mass*JL[i][a]*JL[i][b]; D->M[a][b]+=s; }
+      real s=0; for (int i=0;i<3;i++) s += JA[i][a]*nA[i] + JL[i][a]*fL[i]; D->h[a]+=s;
+    }
+  }
+  for (int a=0;a<NU;a++) for (int b=0;b<a;b++) D->M[a][b]=D->M[b][a];
+  /* tips */
+  for (int i=0;i<4;i++) {
+    int tb=m->tip_body[i]; real off[3], t[3]; for (int j=0;j<3;j++) off[j]=(real)m->tip_off[i][j];
+    m3v(K.Rw[tb], off, t); for (int j=0;j<3;j++) D->tip[i][j]=K.ow[tb][j]+t[j];
+    real JLt[3][LMO_NTREE]; memset(JLt,0,sizeof(JLt)); memset(D->Jt[i],0,sizeof(D->Jt[i]));
+    for (int j=tb; m->parent[j]>=0; j=m->parent[j]) { real r[3], tt[3]; for (int a=0;a<3;a++) r[a]=D->tip[i][a]-K.ow[j][a];
+      cross(K.zw[j], r, tt); for (int a=0;a<3;a++) JLt[a][m->dof[j]]=tt[a]; }
+    for (int a=0;a<3;a++) for (int c=0;c<LMO_NQ;c++) { real s=0; for (int tt=0;tt<LMO_NTREE;tt++) s+=JLt[a][tt]*K.G[tt][c]; D->Jt[i][a][6+c]=s; }
+    if (floating) { real r[3]; for (int a=0;a<3;a++) r[a]=D->tip[i][a]-D->p0[a];
+      for (int c=0;c<3;c++) { real col[3]={D->R0[c],D->R0[3+c],D->R0[6+c]}, tt[3]; cross(col, r, tt);
+        for (int a=0;a<3;a++) { D->Jt[i][a][c]=tt[a]; D->Jt[i][a][3+c]=col[a]; } } }
+  }
+  if (!floating) {
+    /* plate: spatial inertia about plate origin in plate coordinates, u = [w_b, v_b] */
+    real mp=(real)p->plate_mass, c[3], Ic[3]; for (int i=0;i<3;i++){c[i]=(real)p->plate_com[i]; Ic[i]=(real)p->plate_inertia[i];}
+    real IO[3][3]; real cc=dot3(c,c);
+    for (int i=0;i<3;i++) for (int j=0;j<3;j++) IO[i][j]=(i==j?Ic[i]+mp*cc:0)-mp*c[i]*c[j];
+    real cx[3][3]={{0,-c[2],c[1]},{c[2],0,-c[0]},{-c[1],c[0],0}};
+    for (int i=0;i<3;i++) for (int j=0;j<3;j++) { D->M[i][j]=IO[i][j]; D->M[i][3+j]=mp*cx[i][j]; D->M[3+i][j]=-mp*cx[i][j]; D->M[3+i][3+j]=(i==j)?mp:0; }
+    real wpl[3], vpl[3]; m3Tv(D->Rf, phys+47, wpl); m3Tv(D->Rf, phys+44, vpl);
+    /* momentum: n = IO w + m c x v ; f = m v - m c x w */
+    real n[3], f[3], t[3], t2[3];
+    for (int i=0;i<3;i++) n[i]=IO[i][0]*wpl[0]+IO[i][1]*wpl[1]+IO[i][2]*wpl[2];
+    cross(c, vpl, t); for (int i=0;i<3;i++) n[i]+=mp*t[i];
+    cross(c, wpl, t); for (int i=0;i<3;i++) f[i]=mp*(vpl[i]-t[i]);
+    /* v x* [n;f] = [w x n + v x f ; w x f] */
+    cross(wpl, n, t); cross(vpl, f, t2); for (int i=0;i<3;i++) D->h[i]=t[i]+t2[i];
+    cross(wpl, f, t); for (int i=0;i<3;i++) D->h[3+i]=t[i];
+    /* gravity force in plate coords at COM */
+    real gw[3]={0,0,-(real)p->gravity}, gb[3]; m3Tv(D->Rf, gw, gb);
+    real fg[3]={mp*gb[0],mp*gb[1],mp*gb[2]}, ng[3]; cross(c, fg, ng);
+    for (int i=0;i<3;i++) { D->h[i]-=ng[i]; D->h[3+i]-=fg[i]; }
+  }
+}
+
+void lmo_dyn_terms(const lmo_model* m, const lmo_params* p, const real* phys, real* M, real* h) {
+  dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t)); dyn_compute(m, p, phys, D);
+  for (int a=0;a<NU;a++) { for (int b=0;b<NU;b++) M[a*NU+b]=D->M[a][b]; h[a]=D->h[a]; }
+  free(D);
+}
+
+/* Cholesky (lower) in place; returns 0 on success */
+static int chol(real A[NU][NU]) {
+  for (int j=0;j<NU;j++) { real s=A[j][j]; for (int k=0;k<j;k++) s-=A[j][k]*A[j][k]; if (s<=0) return 1; real d=sqrt(s); A[j][j]=d;
+    for (int i=j+1;i<NU;i++) { real t=A[i][j]; for (int k=0;k<j;k++) t-=A[i][k]*A[j][k]; A[i][j]=t/d; } }
+  return 0;
+}
+static void chol_solve(real L[NU][NU], const real* b, real* x) {
+  real y[NU]; for (int i=0;i<NU;i++) { real s=b[i]; for (int k=0;k<i;k++) s-=L[i][k]*y[k]; y[i]=s/L[i][i]; }
+  for (int i=NU-1;i>=0;i--) { real s=y[i]; for (int k=i+1;k<NU;k++) s-=L[k][i]*x[k]; x[i]=s/L[i][i]; }
+}
+
+static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, const real* target) {
+  dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t));
+  dyn_compute(m, p, phys, D);
+  const real dt=(real)p->dt, kd=(real)p->kd, tmax=(real)p->tau_max, mu=(real)p->mu;
+  real u[NU];
+  if (p->mode==0) { m3Tv(D->R0, phys+10, u); m3Tv(D->R0, phys+7, u+3); }
+  else { m3Tv(D->Rf, phys+47, u); m3Tv(D->Rf, phys+44, u+3); }
+  for (int j=0;j<12;j++) u[6+j]=phys[25+j];
+  /* contact geometry */
+  real Jc[12][NU], bn[4]; memset(Jc,0,sizeof(Jc));
+  for (int i=0;i<4;i++) {
+    real n[3], t1[3], t2[3], phi; real Jrel[3][NU]; memcpy(Jrel, D->Jt[i], sizeof(Jrel));
+    if (p->mode==0) { n[0]=0;n[1]=0;n[2]=1; t1[0]=1;t1[1]=0;t1[2]=0; t2[0]=0;t2[1]=1;t2[2]=0; phi=D->tip[i][2]-(real)p->tip_radius; }
+    else {
+      real d[3], y0[3], y[3]; for (int a=0;a<3;a++) d[a]=D->tip[i][a]-D->pf[a]; m3Tv(D->Rf, d, y0);
+      for (int a=0;a<3;a++) y[a]=y0[a]-(real)p->plate_center[a];
+      real sgn = (y[2]>=0)?1:-1; real ez[3]={0,0,sgn}, ex[3]={1,0,0};
+      m3v(D->Rf, ez, n); m3v(D->Rf, ex, t1); cross(n, t1, t2);
+      phi = sgn*y[2]-(real)p->plate_half[2]-(real)p->tip_radius;
+      if (fabs(y[0])>(real)p->plate_half[0] || fabs(y[1])>(real)p->plate_half[1]) phi = 1.0e3;
+      /* subtract plate point velocity: R_p (v_b + w_b x y0) */
+      for (int c=0;c<3;c++) { real col[3]={D->Rf[c],D->Rf[3+c],D->Rf[6+c]}; real ec[3]={0,0,0}; ec[c]=1; real cy[3], t[3]; cross(ec, y0, cy); m3v(D->Rf, cy, t);
+        for (int a=0;a<3;a++) { Jrel[a][c]-=t[a]; Jrel[a][3+c]-=col[a]; } }
+    }
+    for (int a=0;a<NU;a++) { real jn=0,j1=0,j2=0; for (int r=0;r<3;r++){ jn+=n[r]*Jrel[r][a]; j1+=t1[r]*Jrel[r][a]; j2+=t2[r]*Jrel[r][a]; }
+      Jc[3*i][a]=jn; Jc[3*i+1][a]=j1; Jc[3*i+2][a]=j2; }
+    if (phi>=0) bn[i]=phi/dt; else { real b=(real)p->baumgarte*phi/dt; if (b<-(real)p->max_depen_vel) b=-(real)p->max_depen_vel; bn[i]=b; }
+  }
+  int sat[12]; real tsat[12]; for (int j=0;j<12;j++){sat[j]=0;tsat[j]=0;}
+  real un[NU];
+  for (int pass=0; pass<2; pass++) {
+    real L[NU][NU]; memcpy(L, D->M, sizeof(L)); real rhs[NU];
+    for (int a=0;a<NU;a++) rhs[a]=-D->h[a];
+    for (int j=0;j<12;j++) { if (!sat[j]) { L[6+j][6+j]+=dt*kd; rhs[6+j]+=kd*(target[j]-u[6+j]); } else rhs[6+j]+=tsat[j]; }
+    chol(L);
+    real acc[NU], uf[NU]; chol_solve(L, rhs, acc); for (int a=0;a<NU;a++) uf[a]=u[a]+dt*acc[a];
+    real MiJ[12][NU], W[12][12], vf[12], lam[12];
+    for (int r=0;r<12;r++) { chol_solve(L, Jc[r], MiJ[r]); }
+    for (int r=0;r<12;r++) { for (int c=0;c<12;c++){ real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*MiJ[c][a]; W[r][c]=s; }
+      real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*uf[a]; vf[r]=s; lam[r]=0; }
+    for (int it=0; it<p->pgs_iters; it++) for (int i=0;i<4;i++) {
+      int r=3*i; real v=vf[r]+bn[i]; for (int c=0;c<12;c++) v+=W[r][c]*lam[c];
+      real ln=lam[r]-v/W[r][r]; if (ln<0) ln=0; lam[r]=ln;
+      for (int k=1;k<3;k++) { int rr=r+k; real vt=vf[rr]; for (int c=0;c<12;c++) vt+=W[rr][c]*lam[c];
+        real lt=lam[rr]-vt/W[rr][rr]; real lim=mu*lam[r]; if (lt>lim) lt=lim; if (lt<-lim) lt=-lim; lam[rr]=lt; }
+    }
+    for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
+    if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); if (tau>tmax){sat[j]=1;tsat[j]=tmax;any=1;} else if (tau<-tmax){sat[j]=1;tsat[j]=-tmax;any=1;} }
+      if (!any) break; }
+  }
+  /* integrate */
+  for (int j=0;j<12;j++) { phys[25+j]=un[6+j]; phys[13+j]+=dt*un[6+j]; }
+  {
+    real* pos  = (p->mode==0)? phys   : phys+37;
+    real* quat = (p->mode==0)? phys+3 : phys+40;
+    real* lin  = (p->mode==0)? phys+7 : phys+44;
+    real* ang  = (p->mode==0)? phys+10: phys+47;
+    real ww[3]; m3v(D->Rf, un, ww);
+    real th = sqrt(dot3(ww,ww))*dt, dq[4];
+    if (th < (real)1e-8) { dq[0]=1; for (int a=0;a<3;a++) dq[1+a]=(real)0.5*dt*ww[a]; }
+    else { real s=sin(th*(real)0.5)/(th/dt); dq[0]=cos(th*(real)0.5); for (int a=0;a<3;a++) dq[1+a]=s*ww[a]; }
+    real qn[4]; quat_mul(dq, quat, qn); real nn=sqrt(qn[0]*qn[0]+qn[1]*qn[1]+qn[2]*qn[2]+qn[3]*qn[3]);
+    for (int a=0;a<4;a++) quat[a]=qn[a]/nn;
+    real Rn[9], vw[3]; quat_to_mat(quat, Rn); m3v(Rn, un+3, vw);
+    for (int a=0;a<3;a++) { ang[a]=ww[a]; lin[a]=vw[a]; pos[a]+=dt*vw[a]; }
+  }
+  free(D);
+}
+
+void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets) {
+  for (int e=0;e<N;e++) substep_one(m, p, phys+(size_t)e*LMO_PHYS, targets+(size_t)e*12);
+}
+
+/* ------------------------------------------------------------------ task layer */
+static void quat_rotate_inverse(const real* q, const real* v, real* o) { real R[9]; quat_to_mat(q,R); m3Tv(R,v,o); }
+
+void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real* actions,
+                   real* task, int64_t* cnt, real* obs, real* states, real* rew, real* terms) {
+  for (int e=0;e<N;e++) {
+    const real* rb=readback+(size_t)e*LMO_READBACK; const real* act=actions+(size_t)e*12;
+    real* tk=task+(size_t)e*LMO_TASK; int64_t* c=cnt+(size_t)e*LMO_CNT;
+    real* ob=obs+(size_t)e*64; real* st=states+(size_t)e*93; real* tr=terms+(size_t)e*LMO_TERMS;
+    const real *q=rb, *qd=rb+12, *acc=rb+24, *bp=rb+36, *bq=rb+39, *lv=rb+43, *av=rb+46, *tips=rb+49, *knees=rb+61;
+    real* last_act=tk; real* last_tip=tk+24; real* goal=tk+36;
+    /* post_physics_step: progress_buf += 1 (rl_task.py:251) */
+    c[4]+=1;
+    real opos[3], oquat[4], olin[3], oang[3], btip[12];
+    real Rr[9], pr[3];
+    if (p->mode==0) {
+      /* quadruped_pose_control.py:319-335 */
+      real nb[3]={-bp[0],-bp[1],-bp[2]}, nl[3]={-lv[0],-lv[1],-lv[2]}, na[3]={-av[0],-av[1],-av[2]};
+      quat_rotate_inverse(bq, nb, opos); quat_conj(bq, oquat); quat_rotate_inverse(bq, nl, olin); quat_rotate_inverse(bq, na, oang);
+      quat_to_mat(bq, Rr); for (int i=0;i<3;i++) pr[i]=bp[i];
+    } else {
+      /* quadruped_manipulate_plate.py:323-343 */
+      real qr[4]; for (int i=0;i<4;i++) qr[i]=(real)p->fixed_base_quat[i]; for (int i=0;i<3;i++) pr[i]=(real)p->fixed_base_pos[i];
+      quat_to_mat(qr, Rr);
+      real d[3]={bp[0]-pr[0],bp[1]-pr[1],bp[2]-pr[2]}; m3Tv(Rr, d, opos);
+      real qc[4]; quat_conj(qr, qc); quat_mul(qc, bq, oquat); if (oquat[0]<0) for (int i=0;i<4;i++) oquat[i]=-oquat[i];
+      m3Tv(Rr, lv, olin); m3Tv(Rr, av, oang);
+    }
+    for (int i=0;i<4;i++) { real d[3]={tips[3*i]-pr[0],tips[3*i+1]-pr[1],tips[3*i+2]-pr[2]}; m3Tv(Rr, d, btip+3*i); }
+    real gc[4], qdiff[4]; quat_conj(goal, gc); quat_mul(oquat, gc, qdiff);
+    real qdf[4]; for (int i=0;i<4;i++) qdf[i]=(qdiff[0]<0)?-qdiff[i]:qdiff[i];
+    real Ro[9]; quat_to_mat(oquat, Ro); real up[3]={Ro[2],Ro[5],Ro[8]};
+    int k=0;
+    for (int i=0;i<3;i++) ob[k++]=(real)p->s_pos*opos[i];
+    for (int i=0;i<3;i++) ob[k++]=up[i];
+    for (int i=0;i<4;i++) ob[k++]=qdf[i];
+    for (int i=0;i<3;i++) ob[k++]=(real)p->s_lin*olin[i];
+    for (int i=0;i<3;i++) ob[k++]=(real)p->s_ang*oang[i];
+    for (int i=0;i<12;i++) ob[k++]=(real)p->s_q*q[i];
+    for (int i=0;i<12;i++) ob[k++]=(real)p->s_qd*qd[i];
+    for (int i=0;i<12;i++) ob[k++]=act[i];
+    for (int i=0;i<12;i++) ob[k++]=last_act[i];
+    k=0;
+    for (int i=0;i<3;i++) st[k++]=(real)p->s_pos*opos[i];
+    for (int i=0;i<3;i++) st[k++]=(real)p->s_lin*olin[i];
+    for (int i=0;i<4;i++) st[k++]=oquat[i];
+    for (int i=0;i<3;i++) st[k++]=(real)p->s_ang*oang[i];
+    for (int i=0;i<12;i++) st[k++]=(real)p->s_q*q[i];
+    for (int i=0;i<12;i++) st[k++]=(real)p->s_qd*qd[i];
+    for (int i=0;i<4;i++) st[k++]=goal[i];
+    for (int i=0;i<4;i++) st[k++]=qdf[i];
+    for (int i=0;i<12;i++) st[k++]=btip[i];
+    for (int i=0;i<12;i++) st[k++]=last_tip[i];
+    for (int i=0;i<12;i++) st[k++]=act[i];
+    for (int i=0;i<12;i++) st[k++]=last_act[i];
+    for (int i=0;i<12;i++) last_tip[i]=btip[i];
+    /* calculate_metrics (quadruped_pose_control.py:428-548) */
+    real vn=sqrt(qdiff[1]*qdiff[1]+qdiff[2]*qdiff[2]+qdiff[3]*qdiff[3]); if (vn>1) vn=1;
+    real rot_dist=2*asin(vn);
+    real rot_rew=(real)p->quat_scale/(fabs(rot_dist)+(real)p->rot_eps);
+    real trans=sqrt(opos[0]*opos[0]+opos[1]*opos[1])*(real)p->trans_scale;
+    real accp=0, rate=0; for (int i=0;i<12;i++){ accp+=fabs(acc[i])*(real)p->acc_scale; rate+=fabs(last_act[i]-act[i]); } rate*=(real)p->rate_scale;
+    int64_t cgr=(c[1]>p->max_consec)?1:0;
+    real bonus=(real)p->bonus*(real)cgr;
+    int64_t succ=(fabs(rot_dist)<=(real)p->succ_thresh)?1:0;
+    int brk=0, rst=0;
+    for (int l=0;l<4;l++) {
+      real dd=fabs(q[5+2*l]-q[4+2*l]);
+      if (dd<(real)p->d23_pen[0]||dd>(real)p->d23_pen[1]) brk++;
+      if (dd<(real)p->d23_rst[0]||dd>(real)p->d23_rst[1]) rst++;
+      if (q[l]<(real)p->d1_pen[l][0]||q[l]>(real)p->d1_pen[l][1]) brk++;
+      if (q[l]<(real)p->d1_rst[l][0]||q[l]>(real)p->d1_rst[l][1]) rst++;
+    }
+    real limp=(brk>0)?(real)p->limit_pen:0;
+    real total=rot_rew+trans+accp+rate+bonus+limp;
+    c[2]=cgr;
+    int64_t both=(succ&&c[0])?1:0;
+    if (!both) c[1]=0; else c[1]=c[1]+1;
+    if (c[0]==0 && succ==1) c[1]=1;
+    c[0]=succ;
+    for (int i=0;i<12;i++) last_act[i]=act[i];
+    /* is_done (quadruped_pose_control.py:562-616 / quadruped_manipulate_plate.py:569-640) */
+    int64_t reset=c[3];
+    if (opos[2]>0) reset=1;
+    {
+      /* heights are measured in the "object" frame: ground (identity) for loco, plate for mani */
+      real Rp[9], pp[3];
+      if (p->mode==0) { for (int i=0;i<9;i++) Rp[i]=(i%4==0)?1:0; pp[0]=pp[1]=pp[2]=0; }
+      else { quat_to_mat(bq, Rp); for (int i=0;i<3;i++) pp[i]=bp[i]; }
+      real d[3], o[3];
+      for (int i=0;i<3;i++) d[i]=pr[i]-pp[i];
+      m3Tv(Rp,d,o); if (o[2]<=(real)p->h_base) reset=1;
+      int nc=0, nk=0;
+      for (int i=0;i<4;i++) { real cb[3], cw[3];
+        for (int a=0;a<3;a++) cb[a]=(real)p->corner[i][a];
+        m3v(Rr, cb, cw); for (int a=0;a<3;a++) d[a]=cw[a]+pr[a]-pp[a];
+        m3Tv(Rp,d,o); if (o[2]<(real)p->h_corner) nc++; }
+      for (int i=0;i<8;i++) { for (int a=0;a<3;a++) d[a]=knees[3*i+a]-pp[a];
+        m3Tv(Rp,d,o); if (o[2]-(real)p->h_knee<=0) nk++; }
+      if (nc>0) reset=1;
+      if (nk>0) reset=1;
+    }
+    if (rst>0) reset=1;
+    real fallp=(real)p->fall_pen*(real)reset;
+    total+=fallp;
+    if (cgr==1) reset=1;
+    if (c[4]>=p->max_episode-1) reset=1;
+    c[3]=reset;
+    rew[e]=total;
+    tr[0]=rot_rew; tr[1]=trans; tr[2]=accp; tr[3]=rate; tr[4]=bonus; tr[5]=limp; tr[6]=fallp; tr[7]=(real)cgr;
+  }
+}
+
+/* ------------------------------------------------------------------ reset + full step */
+void lmo_reset(const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
+               const real* goal_rand, uint32_t seed) {
+  for (int e=0;e<N;e++) {
+    int64_t* c=cnt+(size_t)e*LMO_CNT; if (c[3]==0) continue;
+    real* ph=phys+(size_t)e*LMO_PHYS; real* tk=task+(size_t)e*LMO_TASK;
+    /* quadruped_pose_control.py:230-299 */
+    real u3[3];
+    if (goal_rand) { for (int i=0;i<3;i++) u3[i]=goal_rand[3*e+i]; }
+    else lmo_hash_uniform3(seed, (uint32_t)e, (uint32_t)c[5], u3);
+    real eul[3]; for (int i=0;i<3;i++) eul[i]=(real)p->goal_lo[i]+((real)p->goal_hi[i]-(real)p->goal_lo[i])*u3[i];
+    lmo_quat_from_euler(eul[0], eul[1], eul[2], tk+36);
+    for (int i=0;i<12;i++) { ph[13+i]=(real)p->init_q[i]; ph[25+i]=0; tk[i]=0; tk[12+i]=0; tk[24+i]=(real)p->default_tip[i]; }
+    for (int i=0;i<3;i++) { ph[i]=(real)p->init_base_pos[i]; ph[7+i]=0; ph[10+i]=0; ph[37+i]=(real)p->init_plate_pos[i]; ph[44+i]=0; ph[47+i]=0; }
+    for (int i=0;i<4;i++) { ph[3+i]=(real)p->init_base_quat[i]; ph[40+i]=(real)p->init_plate_quat[i]; }
+    c[0]=0; c[1]=0; c[2]=0; c[3]=0; c[4]=0; c[5]+=1;
+  }
+}
+
+void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
+              const real* actions, const real* goal_rand, uint32_t seed,
+              real* obs, real* states, real* rew, real* terms) {
+  lmo_reset(p, N, phys, task, cnt, goal_rand, seed);
+  real* targets=(real*)malloc(sizeof(real)*12*(size_t)N);
+  real* rb=(real*)malloc(sizeof(real)*LMO_READBACK*(size_t)N);
+  /* robot.py:452-454: velocity mode, unscale_transform(a, -lim, +lim) = a*lim */
+  for (size_t i=0;i<(size_t)N*12;i++) targets[i]=actions[i]*(real)p->act_scale;
+  for (int s=0;s<p->substeps;s++) lmo_substep(m, p, N, phys, targets);
+  for (int e=0;e<N;e++) {
+    real* ph=phys+(size_t)e*LMO_PHYS; real* tk=task+(size_t)e*LMO_TASK; real* r=rb+(size_t)e*LMO_READBACK;
+    for (int i=0;i<12;i++) { r[i]=ph[13+i]; r[12+i]=ph[25+i];
+      r[24+i]=(ph[25+i]-tk[12+i])/(real)p->ctrl_dt;   /* robot.py:290 */
+      tk[12+i]=ph[25+i]; }
+    const real* src=(p->mode==0)?ph:ph+37;
+    for (int i=0;i<13;i++) r[36+i]=src[i];
+    lmo_fk(m, p, ph, r+49, r+61); r[85]=r[86]=0;
+  }
+  lmo_task_eval(p, N, rb, actions, task, cnt, obs, states, rew, terms);
+  free(targets); free(rb);
+}

@@ -1,0 +1,153 @@
+/*
+ * lm_oracle.h -- CPU oracle for the loco-manipulation physics-step engine.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package may import, link or
+ * execute this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.
+ *
+ * What it restates:
+ *   - task layer (obs / reward / termination / reset bookkeeping): the reference's
+ *     RobotLearning/omniisaacgymenvs/tasks/quadruped_pose_control_tasks/quadruped_pose_control.py
+ *     :230-299 (reset_idx), :301-426 (get_observations), :428-560 (calculate_metrics),
+ *     :562-633 (is_done); manipulation deltas quadruped_manipulate_plate.py:311-435,569-652;
+ *     robot/base/robot.py:276-321 (state read-back), :444-461 (take_action);
+ *     utils/math.py:33-193.  PINNED by golden vectors generated from the reference's
+ *     own Python (tests/golden/task_*.npz, tools/gen_golden.py).
+ *   - physics (reference row a7 = closed-source PhysX, absent from /root/reference):
+ *     PARITY UNPINNED against PhysX.  The oracle is a float64 restatement of this
+ *     repo's own physics specification written with a
+ *     deliberately different algorithm from the HIP kernel (dense Jacobian
+ *     projection + Cholesky instead of limb-aggregate articulated-body sweeps),
+ *     pinned only by the weak facts of SURVEY 8(c): FK known answer, loop closure,
+ *     mass, .npy row 0 envelope, analytic cases.
+ *
+ * Build:  make -C oracle   (gcc -O2 -shared; -DLMO_FLOAT for the fp32 variant)
+ */
+#ifndef LM_ORACLE_H
+#define LM_ORACLE_H
+#include <stdint.h>
+
+#ifdef LMO_FLOAT
+typedef float real;
+#else
+typedef double real;
+#endif
+
+#define LMO_MAXB 24      /* bodies incl. root */
+#define LMO_NTREE 20     /* tree DoF (12 driven + 8 passive) */
+#define LMO_NQ 12        /* independent joint coordinates */
+
+typedef struct {
+  int32_t nb;                    /* number of bodies incl. root (21) */
+  int32_t parent[LMO_MAXB];      /* parent body index, -1 for root */
+  int32_t dof[LMO_MAXB];         /* tree DoF index moved by this body's joint, -1 root */
+  double Rt[LMO_MAXB][9];        /* parent body frame -> joint frame at q=0 (row major) */
+  double pt[LMO_MAXB][3];
+  double axis[LMO_MAXB][3];      /* joint axis in joint frame */
+  double mass[LMO_MAXB];
+  double com[LMO_MAXB][3];       /* in body frame */
+  double inertia[LMO_MAXB][9];   /* about COM, body axes */
+  /* loop-closure embedding: passive tree dof p = sgn * g(q[a]-q[b]), g(D)=2 atan(sqrt2 tan(D/2)) */
+  int32_t nclos;
+  int32_t clos_p[8], clos_a[8], clos_b[8];
+  double clos_s[8];
+  int32_t tip_body[4];
+  double tip_off[4][3];
+  int32_t knee_body[8];
+} lmo_model;
+
+typedef struct {
+  /* physics */
+  double dt;                 /* 0.0083 */
+  int32_t substeps;          /* controlFrequencyInv = 4 */
+  int32_t pgs_iters;         /* contact sweeps per solve */
+  double gravity;            /* 9.81 (acts along -z world) */
+  double kd;                 /* velocity-drive damping 100 */
+  double tau_max;            /* 1.5 */
+  double act_scale;          /* velocity limit used for action scaling, 3.0 */
+  double mu;                 /* tip friction coefficient */
+  double tip_radius;
+  double baumgarte;          /* penetration push-out fraction per step */
+  double max_depen_vel;      /* m/s cap on push-out */
+  int32_t mode;              /* 0 = free base on ground (loco), 1 = fixed inverted base + plate (mani) */
+  int32_t pad0;
+  double fixed_base_pos[3];
+  double fixed_base_quat[4];
+  double plate_mass;
+  double plate_com[3];
+  double plate_inertia[3];   /* diagonal about COM, plate axes */
+  double plate_half[3];      /* collider half extents */
+  double plate_center[3];    /* collider centre in plate frame */
+  /* reset (reset_idx) */
+  double init_q[12];
+  double init_base_pos[3];
+  double init_base_quat[4];
+  double init_plate_pos[3];
+  double init_plate_quat[4];
+  double default_tip[12];    /* default_base_tip_positions */
+  double goal_lo[3], goal_hi[3];   /* roll/pitch/yaw ranges */
+  /* observation scales */
+  double s_pos, s_lin, s_ang, s_q, s_qd;
+  /* reward */
+  double quat_scale, rot_eps, trans_scale, acc_scale, rate_scale, bonus, limit_pen, fall_pen;
+  double succ_thresh;
+  int32_t max_consec;        /* 15 */
+  int32_t max_episode;       /* 300 */
+  double d23_pen[2], d23_rst[2];   /* |dof3-dof2| penalty / reset windows */
+  double d1_pen[4][2], d1_rst[4][2]; /* per-limb dof1 windows */
+  double h_base, h_corner, h_knee;
+  double corner[4][3];       /* frame corner points in the robot base frame */
+  double ctrl_dt;            /* dt*substeps, for joint acceleration */
+} lmo_params;
+
+/* per-env physical state, env-major */
+#define LMO_PHYS 50
+/*  0:3 base_pos  3:7 base_quat(wxyz)  7:10 base_linvel(world) 10:13 base_angvel(world)
+ * 13:25 q  25:37 qd  37:40 plate_pos 40:44 plate_quat 44:47 plate_linvel 47:50 plate_angvel */
+#define LMO_TASK 40
+/*  0:12 last_actions 12:24 last_qd 24:36 last_base_tip 36:40 goal_quat */
+#define LMO_CNT 6
+/*  successes, consecutive_successes, goal_reset_buf, reset_buf, progress_buf, episode_count */
+#define LMO_READBACK 87
+/*  0:12 q 12:24 qd 24:36 acc 36:39 base_pos 39:43 base_quat 43:46 linvel 46:49 angvel
+ *  49:61 tips(4x3) 61:85 knees(8x3) 85:87 unused
+ *  (mani: base_* slots hold the plate pose/velocity; robot pose is params.fixed_base_*) */
+#define LMO_TERMS 8
+/*  rot_rew, translation_penalty, joint_acc_penalty, action_rate_penalty,
+ *  consecutive_successes_rew, joint_limit_penalty, fall_penalty, goal_reset (as real) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kinematics of one env: world tips (4x3) and knees (8x3) */
+void lmo_fk(const lmo_model* m, const lmo_params* p, const real* phys, real* tips, real* knees);
+
+/* one physics sub-step for N envs; targets = joint velocity targets (N x 12) */
+void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets);
+
+/* dense dynamics terms of one env (debug/tests): M (18x18 row major), h (18) */
+void lmo_dyn_terms(const lmo_model* m, const lmo_params* p, const real* phys, real* M, real* h);
+
+/* task layer on explicit read-back inputs (golden-vector entry point) */
+void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real* actions,
+                   real* task, int64_t* cnt, real* obs, real* states, real* rew, real* terms);
+
+/* reset of flagged envs (cnt reset_buf != 0); goal_rand may be NULL -> hash RNG(seed) */
+void lmo_reset(const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
+               const real* goal_rand, uint32_t seed);
+
+/* full env step: reset flagged -> targets -> substeps -> readback -> task_eval */
+void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
+              const real* actions, const real* goal_rand, uint32_t seed,
+              real* obs, real* states, real* rew, real* terms);
+
+/* goal sampling helpers exposed for tests */
+void lmo_hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, real* u3);
+void lmo_quat_from_euler(real roll, real pitch, real yaw, real* q);
+int lmo_sizeof_real(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

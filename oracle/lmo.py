@@ -1,0 +1,181 @@
+"""ctypes binding of the CPU oracle (oracle/lm_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+The model / params objects are duck-typed (attributes of RobotModel / EngineParams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+MAXB, NTREE, NQ = 24, 20, 12
+PHYS, TASK, CNT, READBACK, TERMS = 50, 40, 6, 87, 8
+
+
+class LmoModel(C.Structure):
+    _fields_ = [
+        ("nb", C.c_int32), ("parent", C.c_int32 * MAXB), ("dof", C.c_int32 * MAXB),
+        ("Rt", (C.c_double * 9) * MAXB), ("pt", (C.c_double * 3) * MAXB), ("axis", (C.c_double * 3) * MAXB),
+        ("mass", C.c_double * MAXB), ("com", (C.c_double * 3) * MAXB), ("inertia", (C.c_double * 9) * MAXB),
+        ("nclos", C.c_int32), ("clos_p", C.c_int32 * 8), ("clos_a", C.c_int32 * 8), ("clos_b", C.c_int32 * 8),
+        ("clos_s", C.c_double * 8),
+        ("tip_body", C.c_int32 * 4), ("tip_off", (C.c_double * 3) * 4), ("knee_body", C.c_int32 * 8),
+    ]
+
+
+class LmoParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double), ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("gravity", C.c_double),
+        ("kd", C.c_double), ("tau_max", C.c_double), ("act_scale", C.c_double), ("mu", C.c_double),
+        ("tip_radius", C.c_double), ("baumgarte", C.c_double), ("max_depen_vel", C.c_double),
+        ("mode", C.c_int32), ("pad0", C.c_int32),
+        ("fixed_base_pos", C.c_double * 3), ("fixed_base_quat", C.c_double * 4),
+        ("plate_mass", C.c_double), ("plate_com", C.c_double * 3), ("plate_inertia", C.c_double * 3),
+        ("plate_half", C.c_double * 3), ("plate_center", C.c_double * 3),
+        ("init_q", C.c_double * 12), ("init_base_pos", C.c_double * 3), ("init_base_quat", C.c_double * 4),
+        ("init_plate_pos", C.c_double * 3), ("init_plate_quat", C.c_double * 4), ("default_tip", C.c_double * 12),
+        ("goal_lo", C.c_double * 3), ("goal_hi", C.c_double * 3),
+        ("s_pos", C.c_double), ("s_lin", C.c_double), ("s_ang", C.c_double), ("s_q", C.c_double), ("s_qd", C.c_double),
+        ("quat_scale", C.c_double), ("rot_eps", C.c_double), ("trans_scale", C.c_double), ("acc_scale", C.c_double),
+        ("rate_scale", C.c_double), ("bonus", C.c_double), ("limit_pen", C.c_double), ("fall_pen", C.c_double),
+        ("succ_thresh", C.c_double), ("max_consec", C.c_int32), ("max_episode", C.c_int32),
+        ("d23_pen", C.c_double * 2), ("d23_rst", C.c_double * 2),
+        ("d1_pen", (C.c_double * 2) * 4), ("d1_rst", (C.c_double * 2) * 4),
+        ("h_base", C.c_double), ("h_corner", C.c_double), ("h_knee", C.c_double),
+        ("corner", (C.c_double * 3) * 4), ("ctrl_dt", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle shared objects next to the sources (gcc only)."""
+    if force or not all(os.path.exists(os.path.join(_DIR, f"liblmoracle_{s}.so")) for s in ("f64", "f32")) or \
+            os.path.getmtime(os.path.join(_DIR, "lm_oracle.c")) > os.path.getmtime(os.path.join(_DIR, "liblmoracle_f64.so")):
+        subprocess.check_call(["make", "-C", _DIR, "-s", "-B"])
+
+
+def _set(arr, values):
+    v = np.asarray(values, dtype=np.float64)
+    if v.ndim == 1:
+        for i, x in enumerate(v):
+            arr[i] = float(x)
+    else:
+        for i, row in enumerate(v):
+            for j, x in enumerate(row):
+                arr[i][j] = float(x)
+
+
+def make_model(rm) -> LmoModel:
+    m = LmoModel()
+    m.nb = rm.nb
+    for k in range(rm.nb):
+        m.parent[k] = int(rm.parent[k]); m.dof[k] = int(rm.dof[k]); m.mass[k] = float(rm.mass[k])
+    _set(m.Rt, rm.Rt); _set(m.pt, rm.pt); _set(m.axis, rm.axis); _set(m.com, rm.com); _set(m.inertia, rm.inertia)
+    m.nclos = 8
+    for c in range(8):
+        m.clos_p[c] = int(rm.clos_p[c]); m.clos_a[c] = int(rm.clos_a[c]); m.clos_b[c] = int(rm.clos_b[c])
+        m.clos_s[c] = float(rm.clos_s[c])
+    for i in range(4):
+        m.tip_body[i] = int(rm.tip_body[i])
+    _set(m.tip_off, rm.tip_off)
+    for i in range(8):
+        m.knee_body[i] = int(rm.knee_body[i])
+    return m
+
+
+def make_params(ep) -> LmoParams:
+    p = LmoParams()
+    for name, ctype in LmoParams._fields_:
+        if name == "pad0":
+            continue
+        val = getattr(ep, name)
+        if isinstance(val, (list, tuple, np.ndarray)):
+            _set(getattr(p, name), val)
+        else:
+            setattr(p, name, val)
+    return p
+
+
+class Oracle:
+    """CPU oracle instance (float64 by default; precision='f32' for the float build)."""
+
+    def __init__(self, robot_model, engine_params, precision: str = "f64"):
+        build()
+        self.lib = C.CDLL(os.path.join(_DIR, f"liblmoracle_{precision}.so"))
+        self.dtype = np.float64 if precision == "f64" else np.float32
+        assert self.lib.lmo_sizeof_real() == np.dtype(self.dtype).itemsize
+        self.model = make_model(robot_model)
+        self.params = make_params(engine_params)
+        self._rm, self._ep = robot_model, engine_params
+
+    def set_params(self, engine_params):
+        self.params = make_params(engine_params); self._ep = engine_params
+
+    def _p(self, a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def _arr(self, a, shape=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if shape is not None:
+            assert a.shape == shape, (a.shape, shape)
+        return a
+
+    # -- state helpers ---------------------------------------------------------
+    def new_state(self, N):
+        phys = np.zeros((N, PHYS), self.dtype); phys[:, 3] = 1; phys[:, 40] = 1
+        task = np.zeros((N, TASK), self.dtype); task[:, 36] = 1
+        cnt = np.zeros((N, CNT), np.int64); cnt[:, 3] = 1       # reset_buf starts as ones (rl_task.py:111)
+        return phys, task, cnt
+
+    def fk(self, phys):
+        phys = self._arr(phys); N = phys.shape[0]
+        tips = np.zeros((N, 4, 3), self.dtype); knees = np.zeros((N, 8, 3), self.dtype)
+        for e in range(N):
+            self.lib.lmo_fk(C.byref(self.model), C.byref(self.params), self._p(phys[e]), self._p(tips[e]), self._p(knees[e]))
+        return tips, knees
+
+    def substep(self, phys, targets):
+        assert phys.dtype == self.dtype and phys.flags.c_contiguous
+        targets = self._arr(targets, (phys.shape[0], 12))
+        self.lib.lmo_substep(C.byref(self.model), C.byref(self.params), C.c_int(phys.shape[0]), self._p(phys), self._p(targets))
+
+    def dyn_terms(self, phys_row):
+        phys_row = self._arr(phys_row, (PHYS,))
+        M = np.zeros((18, 18), self.dtype); h = np.zeros(18, self.dtype)
+        self.lib.lmo_dyn_terms(C.byref(self.model), C.byref(self.params), self._p(phys_row), self._p(M), self._p(h))
+        return M, h
+
+    def task_eval(self, readback, actions, task, cnt):
+        N = readback.shape[0]
+        readback = self._arr(readback, (N, READBACK)); actions = self._arr(actions, (N, 12))
+        assert task.dtype == self.dtype and cnt.dtype == np.int64
+        obs = np.zeros((N, 64), self.dtype); states = np.zeros((N, 93), self.dtype)
+        rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype)
+        self.lib.lmo_task_eval(C.byref(self.params), C.c_int(N), self._p(readback), self._p(actions), self._p(task),
+                               self._p(cnt), self._p(obs), self._p(states), self._p(rew), self._p(terms))
+        return obs, states, rew, terms
+
+    def reset(self, phys, task, cnt, goal_rand=None, seed=0):
+        N = phys.shape[0]
+        gr = None if goal_rand is None else self._arr(goal_rand, (N, 3))
+        self.lib.lmo_reset(C.byref(self.params), C.c_int(N), self._p(phys), self._p(task), self._p(cnt),
+                           None if gr is None else self._p(gr), C.c_uint32(seed))
+
+    def step(self, phys, task, cnt, actions, goal_rand=None, seed=0):
+        N = phys.shape[0]
+        actions = self._arr(actions, (N, 12))
+        gr = None if goal_rand is None else self._arr(goal_rand, (N, 3))
+        obs = np.zeros((N, 64), self.dtype); states = np.zeros((N, 93), self.dtype)
+        rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype)
+        self.lib.lmo_step(C.byref(self.model), C.byref(self.params), C.c_int(N), self._p(phys), self._p(task), self._p(cnt),
+                          self._p(actions), None if gr is None else self._p(gr), C.c_uint32(seed),
+                          self._p(obs), self._p(states), self._p(rew), self._p(terms))
+        return obs, states, rew, terms
+
+    def hash_uniform3(self, seed, env, episode):
+        u = np.zeros(3, self.dtype)
+        self.lib.lmo_hash_uniform3(C.c_uint32(seed), C.c_uint32(env), C.c_uint32(episode), self._p(u))
+        return u
