@@ -1,0 +1,98 @@
+"""Model compiler: known answers from the reference's own constants."""
+import os
+
+import numpy as np
+import pytest
+
+from locomanipulationrl_amd.model.robot_model import closure_g, LIMB_STRIDE, HUB_FLOATS
+
+CLASS_DEFAULT_Q = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]
+TASK_Q = [-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09]
+
+
+def test_total_mass(robot_model, vertical_model):
+    assert abs(robot_model.total_mass - 2.2559) < 1e-4
+    assert abs(vertical_model.total_mass - 2.2566) < 1e-4
+
+
+def test_fk_known_answer(robot_model):
+    # quadruped_pose_control.py:127-130 default_base_tip_positions at robot/quadruped_robot.py:45-52 pose
+    expect = np.array([[-0.0937, 0.1223, -0.1774], [0.0937, 0.1408, -0.1773],
+                       [-0.0937, -0.1408, -0.1773], [0.0937, -0.1223, -0.1774]])
+    tips = robot_model.tip_positions(CLASS_DEFAULT_Q)
+    assert np.abs(tips - expect).max() < 1e-4
+    # with the reference's rounded passive angles (+-0.953) the same answer comes out
+    qt = np.array(CLASS_DEFAULT_Q + [0.953, -0.953] * 4)
+    assert np.abs(robot_model.tip_positions(CLASS_DEFAULT_Q, tree_angles=qt) - expect).max() < 1e-4
+
+
+def test_task_pose_tips(robot_model):
+    tips = robot_model.tip_positions(TASK_Q)
+    assert np.abs(tips[0] - [-0.1186, 0.1189, -0.1292]).max() < 5e-4       # SURVEY A.4 (rounded passives there)
+    assert abs(tips[:, 2].mean() + 0.129) < 5e-4                            # -> 0.011 m above ground at base z 0.14
+
+
+def test_vertical_pose(vertical_model):
+    q = [0, 0, 0, 0] + [0.35, -0.35] * 4
+    tips = vertical_model.tip_positions(q)
+    assert np.abs(tips[0] - [-0.079, -0.009, -0.3186]).max() < 5e-4
+
+
+def test_closure_function_values():
+    # passive angles the reference ships: 0.953 at D=0.70, 1.37(26) at D=1.05, 0.95 at D=0.70 (vertical)
+    g, g1, g2 = closure_g(np.array([0.70, 1.05]))
+    assert abs(g[0] - 0.953) < 1e-3 and abs(g[1] - 1.3726) < 1e-4
+    eps = 1e-6
+    gp, _, _ = closure_g(0.9 + eps); gm, _, _ = closure_g(0.9 - eps)
+    _, d1, d2 = closure_g(0.9)
+    assert abs((gp - gm) / (2 * eps) - d1) < 1e-8
+    _, d1p, _ = closure_g(0.9 + eps); _, d1m, _ = closure_g(0.9 - eps)
+    assert abs((d1p - d1m) / (2 * eps) - d2) < 1e-7
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference URDF (build container only)")
+@pytest.mark.parametrize("urdf", ["quadruped_robot_v2", "quadfinger"])
+def test_loop_closure_against_urdf(urdf):
+    """The analytic embedding closes the removed closed_chain_revolute joints of the URDF to < 0.05 mm
+    over the whole admissible range of D = dof2 - dof3 (reset window 0.384..2.61)."""
+    from locomanipulationrl_amd.model.urdf import parse_urdf, build_tree, forward_kinematics, loop_residual
+    links, joints = parse_urdf(f"/root/reference/Design/RobotURDF/robot_urdfs/{urdf}.urdf")
+    tree = build_tree(links, joints)
+    assert len(tree.loops) == 4 and len(tree.bodies) == 21
+    rng = np.random.default_rng(0)
+    for D in np.linspace(0.3, 2.8, 12):
+        q = {}
+        for mod in ("a1", "a2", "a3", "a4"):
+            q2 = rng.uniform(-1, 1); g, _, _ = closure_g(D)
+            q[f"{mod}-dof1"] = rng.uniform(-1, 1); q[f"{mod}-dof2"] = q2; q[f"{mod}-dof3"] = q2 - D
+            for b in tree.bodies:
+                if b.joint_name.startswith(f"{mod}-link4_to_link3"):
+                    q[b.joint_name] = g
+                if b.joint_name.startswith(f"{mod}-link1_to_link2"):
+                    q[b.joint_name] = -g
+        poses = forward_kinematics(tree, q)
+        for lp in tree.loops:
+            gap, ang = loop_residual(tree, poses, lp)
+            assert gap < 5e-5 and ang < 1e-4, (urdf, D, lp.name, gap, ang)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference URDF (build container only)")
+def test_compiled_assets_are_current(robot_model):
+    from locomanipulationrl_amd.model.robot_model import compile_urdf
+    m = compile_urdf("/root/reference/Design/RobotURDF/robot_urdfs/quadruped_robot_v2.urdf")
+    for k in ("Rt", "pt", "mass", "com", "inertia", "tip_off"):
+        assert np.allclose(getattr(m, k), getattr(robot_model, k), atol=1e-12)
+    assert list(m.dof) == list(robot_model.dof)
+
+
+def test_packed_table_layout(robot_model):
+    t = robot_model.packed_table()
+    assert t.dtype == np.float32 and t.shape == (HUB_FLOATS + 4 * LIMB_STRIDE,)
+    assert abs(t[0] - robot_model.mass[0]) < 1e-6
+    # every joint rotation block is orthonormal, every axis sign is +-1
+    for l in range(4):
+        o = HUB_FLOATS + l * LIMB_STRIDE
+        for j in range(5):
+            R = t[o + 13 * j: o + 13 * j + 9].reshape(3, 3).astype(np.float64)
+            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-6
+            assert abs(abs(t[o + 13 * j + 12]) - 1) < 1e-7

@@ -1,0 +1,76 @@
+"""Pins the CPU oracle's task layer to the reference's own Python (golden vectors made by
+tools/gen_golden.py from quadruped_pose_control.py / quadruped_manipulate_plate.py / utils/math.py /
+robot.py).  Tolerances: the reference computes in float32 (and rotates through scipy float64), the
+oracle in float64 -> absolute 2e-6 on O(1) observations, relative 1e-6 on rewards (bonus 600)."""
+import os
+
+import numpy as np
+import pytest
+
+from locomanipulationrl_amd.engine_config import loco_params, mani_params
+from oracle.lmo import Oracle
+from conftest import GOLDEN
+
+# reference extras keys sorted alphabetically -> column of the oracle's per-env reward terms
+EXTRAS_TO_TERM = {"env/rewards/action_rate_penalty": 3, "env/rewards/consecutive_successes_rew": 4,
+                  "env/rewards/fall_penalty": 6, "env/rewards/joint_acc_penalty": 2,
+                  "env/rewards/joint_limit_panelty": 5, "env/rewards/orientation_rew": 0,
+                  "env/rewards/translation_penalty": 1}
+
+
+@pytest.mark.parametrize("kind", ["loco", "mani"])
+def test_task_layer_sequence(robot_model, kind):
+    g = np.load(os.path.join(GOLDEN, f"task_{kind}.npz"))
+    o = Oracle(robot_model, loco_params() if kind == "loco" else mani_params())
+    T, N = g["rew"].shape
+    assert T >= 20
+    phys, task, cnt = o.new_state(N)
+    num_succ = num_rst = 0
+    for t in range(T):
+        o.reset(phys, task, cnt, goal_rand=g["goal_rand"][t])
+        obs, states, rew, terms = o.task_eval(g["readback"][t].astype(np.float64), g["actions"][t], task, cnt)
+        assert np.abs(obs - g["obs"][t]).max() < 2e-6
+        assert np.abs(states - g["states"][t]).max() < 2e-6
+        assert np.allclose(rew, g["rew"][t], rtol=1e-6, atol=2e-6)
+        for name, col in (("successes", 0), ("consecutive_successes", 1), ("goal_reset_buf", 2), ("reset_buf", 3), ("progress_buf", 4)):
+            assert np.array_equal(cnt[:, col], g[name][t]), (name, t)
+        assert np.abs(task[:, 0:12] - g["last_actions"][t]).max() == 0
+        assert np.abs(task[:, 24:36] - g["last_base_tip"][t]).max() < 2e-6
+        assert np.abs(task[:, 36:40] - g["goal_quaternions"][t]).max() < 1e-6
+        for j, key in enumerate(g["extras_keys"]):
+            if str(key) in EXTRAS_TO_TERM:
+                assert abs(terms[:, EXTRAS_TO_TERM[str(key)]].mean() - g["extras"][t][j]) < 1e-5 * max(1, abs(g["extras"][t][j]))
+        # success-rate bookkeeping (quadruped_pose_control.py:618-633) follows from the per-env flags
+        num_succ += int(cnt[:, 2].sum()); num_rst += int(cnt[:, 3].sum())
+        assert num_succ == int(g["num_successes"][t]) and num_rst == int(g["num_resets"][t])
+    assert g["consecutive_successes"].max() > 15 and (g["rew"] > 300).any(), "bonus path must be exercised"
+
+
+def test_quat_from_euler_and_rand_quaternions(robot_model):
+    g = np.load(os.path.join(GOLDEN, "math.npz"))
+    o = Oracle(robot_model, loco_params())
+    lo, hi = np.array([-0.4, -0.4, -1.57]), np.array([0.4, 0.4, 1.57])
+    e = lo + (hi - lo) * g["rand_u"].astype(np.float64)
+    import ctypes as C
+    for i in range(e.shape[0]):
+        q = np.zeros(4)
+        o.lib.lmo_quat_from_euler(C.c_double(e[i, 0]), C.c_double(e[i, 1]), C.c_double(e[i, 2]), q.ctypes.data_as(C.c_void_p))
+        assert np.abs(q - g["rand_quat"][i]).max() < 1e-6
+
+
+def test_take_action_scaling():
+    g = np.load(os.path.join(GOLDEN, "take_action.npz"))
+    a = g["actions"]
+    assert np.allclose(g["velocity"], a * 3.0, atol=1e-6)          # robot.py:452-454 (the mode every task uses)
+    assert np.allclose(g["position"], a * np.float32(np.pi), atol=1e-6)
+    assert np.allclose(g["effort"][:, :12], a * 1.5, atol=1e-6) and np.all(g["effort"][:, 12:] == 0)
+
+
+def test_hash_rng_is_uniform_and_deterministic(robot_model):
+    o = Oracle(robot_model, loco_params())
+    u = np.stack([o.hash_uniform3(42, e, ep) for e in range(64) for ep in range(8)])
+    assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.05
+    assert np.array_equal(o.hash_uniform3(42, 3, 5), o.hash_uniform3(42, 3, 5))
+    assert not np.array_equal(o.hash_uniform3(42, 3, 5), o.hash_uniform3(43, 3, 5))
+    o32 = Oracle(robot_model, loco_params(), "f32")
+    assert np.array_equal(o32.hash_uniform3(42, 3, 5).astype(np.float64), o.hash_uniform3(42, 3, 5))

@@ -1,0 +1,372 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the TASK LAYER from the reference's own Python.
+
+Runs only in the build container (needs /root/reference); the .npz files it writes under
+tests/golden/ are data (inputs + expected outputs) and are what travels to the GPU box.
+
+Method: the reference task classes import Isaac Sim packages that do not exist
+here (ordinary ModuleNotFoundError).  Inert placeholder modules are registered for those
+names so that the reference's *own* torch code in
+    tasks/quadruped_pose_control_tasks/quadruped_pose_control.py   (get_observations,
+        calculate_metrics, is_done, reset_idx, pre_physics_step)
+    tasks/quadruped_manipulate_plate/quadruped_manipulate_plate.py
+    utils/math.py, robot/base/robot.py (take_action)
+executes unmodified on CPU tensors.  The only behaviour supplied from outside the reference
+is the 7 quaternion helpers + unscale_transform of omni.isaac.core.utils.torch (third-party,
+source absent); their semantics are fixed by the call-site evidence listed in SURVEY 8(c)
+and they are unit-tested against scipy in tests/test_math_host.py.
+
+Run:  python -B tools/gen_golden.py
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF_RL = "/root/reference/RobotLearning/omniisaacgymenvs"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- placeholders
+class _Inert:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Inert()
+
+    def __getattr__(self, name):
+        return _Inert()
+
+
+class _InertModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (_Inert,), {})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    ROOTS = ("omni", "pxr", "carb", "gym")
+
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _InertModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def _install_placeholders():
+    sys.meta_path.insert(0, _Finder())
+    rot = types.ModuleType("omni.isaac.core.utils.torch.rotations")
+
+    def quat_mul(a, b):
+        w1, x1, y1, z1 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+        w2, x2, y2, z2 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+        return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+                            w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                            w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                            w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+    def quat_conjugate(a):
+        return torch.cat((a[..., :1], -a[..., 1:]), dim=-1)
+
+    def quat_rotate(q, v):
+        qw, qv = q[:, 0:1], q[:, 1:]
+        return v * (2.0 * qw ** 2 - 1.0) + torch.cross(qv, v, dim=-1) * qw * 2.0 + qv * (qv * v).sum(-1, keepdim=True) * 2.0
+
+    def quat_rotate_inverse(q, v):
+        qw, qv = q[:, 0:1], q[:, 1:]
+        return v * (2.0 * qw ** 2 - 1.0) - torch.cross(qv, v, dim=-1) * qw * 2.0 + qv * (qv * v).sum(-1, keepdim=True) * 2.0
+
+    def quat_axis(q, axis=0):
+        b = torch.zeros(q.shape[0], 3, device=q.device, dtype=q.dtype)
+        b[:, axis] = 1
+        return quat_rotate(q, b)
+
+    def quat_apply(q, v):
+        return quat_rotate(q, v)
+
+    def quat_from_euler_xyz(roll, pitch, yaw):
+        cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
+        cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
+        cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
+        return torch.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp,
+                            cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp], dim=-1)
+
+    for f in (quat_mul, quat_conjugate, quat_rotate, quat_rotate_inverse, quat_axis, quat_apply, quat_from_euler_xyz):
+        setattr(rot, f.__name__, f)
+    maths = types.ModuleType("omni.isaac.core.utils.torch.maths")
+    maths.unscale_transform = lambda x, lower, upper: x * (upper - lower) * 0.5 + (upper + lower) * 0.5
+    import omni.isaac.core.utils.torch  # noqa: F401  (placeholder package)
+    sys.modules[rot.__name__] = rot
+    sys.modules[maths.__name__] = maths
+    # the reference's own omniisaacgymenvs.* imports inside rl_task.py need pxr-heavy modules: make them inert too
+    for name in ("omniisaacgymenvs", "omniisaacgymenvs.tasks", "omniisaacgymenvs.tasks.utils",
+                 "omniisaacgymenvs.tasks.utils.usd_utils", "omniisaacgymenvs.utils",
+                 "omniisaacgymenvs.utils.domain_randomization", "omniisaacgymenvs.utils.domain_randomization.randomize"):
+        m = _InertModule(name); m.__path__ = []
+        sys.modules[name] = m
+    return rot
+
+
+# ----------------------------------------------------------------------------- fakes handed to the reference code
+class FakeRobot:
+    num_modules = 4
+
+    def __init__(self, N):
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32)
+        self.joint_positions, self.joint_velocities, self.joint_accelerations = z(N, 12), z(N, 12), z(N, 12)
+        self.last_joint_velcoties = z(N, 12)
+        self.base_positions, self.base_quaternions = z(N, 3), z(N, 4)
+        self.base_linear_velocities, self.base_angular_velocities = z(N, 3), z(N, 3)
+        self.tip_positions, self.knee_positions = z(N, 4, 3), z(N, 8, 3)
+
+    def __getattr__(self, name):          # every setter / updater is a no-op
+        return lambda *a, **k: None
+
+
+class FakeObj:
+    def __init__(self, N):
+        self.pos = torch.zeros(N, 3); self.quat = torch.zeros(N, 4); self.lin = torch.zeros(N, 3); self.ang = torch.zeros(N, 3)
+
+    def get_object_poses(self):
+        return self.pos, self.quat
+
+    def get_object_velocities(self):
+        return self.lin, self.ang
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+class FakeDR:
+    randomize = False
+
+
+def _rand_unit_quat(g, n, small=None):
+    q = torch.randn(n, 4, generator=g)
+    if small is not None:
+        q = torch.cat((torch.ones(n, 1), small * torch.randn(n, 3, generator=g)), dim=-1)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def make_task(kind, N):
+    if kind == "loco":
+        from tasks.quadruped_pose_control_tasks.quadruped_pose_control import QuadrupedPoseControl as T
+        mangle = "_QuadrupedPoseControl"
+    else:
+        from tasks.quadruped_manipulate_plate.quadruped_manipulate_plate import QuadrupedManipulatePlate as T
+        mangle = "_QuadrupedManipulatePlate"
+    from utils.math import transform_vectors
+    t = object.__new__(T)
+    dev = "cpu"
+    t._device, t._num_envs, t._num_actions, t._num_observations, t._num_states = dev, N, 12, 64, 93
+    t._max_episode_length = 300
+    t._dr_randomizer = FakeDR()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
+    t.obs_buf, t.states_buf, t.rew_buf = z(N, 64), z(N, 93), z(N)
+    t.reset_buf = torch.ones(N, dtype=torch.long); t.progress_buf = z(N, dt=torch.long); t.extras = {}
+    t.last_actions, t.current_actions = z(N, 12), z(N, 12)
+    t.last_base_tip_positions = z(N, 4, 3)
+    t.default_base_tip_positions = torch.tensor([[-0.0937, 0.1223, -0.1774], [0.0937, 0.1408, -0.1773],
+                                                 [-0.0937, -0.1408, -0.1773], [0.0937, -0.1223, -0.1774]]).repeat((N, 1, 1))
+    corner = torch.cat((torch.tensor([0.075, 0.1835, -0.04]).repeat(N, 1), torch.tensor([-0.075, 0.1835, -0.04]).repeat(N, 1),
+                        torch.tensor([0.075, -0.1835, -0.04]).repeat(N, 1), torch.tensor([-0.075, -0.1835, -0.04]).repeat(N, 1)),
+                       dim=-1).view(N, 4, 3).to(torch.float32)
+    setattr(t, mangle + "__corner_pos_robot", corner)
+    t.goal_quaternions = z(N, 4)
+    t.successes, t.consecutive_successes, t.goal_reset_buf = z(N, dt=torch.long), z(N, dt=torch.long), z(N, dt=torch.long)
+    t.max_reset_counts = torch.tensor(2048, dtype=torch.long)
+    t.num_successes = torch.tensor(0, dtype=torch.long); t.num_resets = torch.tensor(0, dtype=torch.long)
+    t.success_rate = torch.tensor(0.0)
+    t.randomization_buf = z(N, dt=torch.long)
+    init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4)
+    if kind == "loco":
+        t.robot_locomotion = FakeRobot(N)
+        t.pose_indicator_loco = FakeObj(N)
+        t.default_joint_positions_loco = init_q.repeat((N, 1))
+        t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.14]).repeat((N, 1))
+        t.default_robot_quaternions_loco = torch.tensor([1.0, 0, 0, 0]).repeat((N, 1))
+        t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
+    else:
+        t.robot_manipulation = FakeRobot(N)
+        t.pose_indicator_mani = FakeObj(N); t.obj = FakeObj(N)
+        t.default_joint_positions_mani = init_q.repeat((N, 1))
+        t.default_robot_positions_mani = torch.tensor([0.0, 0.0, 0.0]).repeat((N, 1))
+        t.default_robot_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
+        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.14]).repeat((N, 1))
+        t.default_obj_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
+        t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
+        setattr(t, mangle + "__corner_pos_world",
+                transform_vectors(t.default_robot_quaternions_mani, t.default_robot_positions_mani, corner, dev))
+    return t
+
+
+def gen_task(kind, N=32, T=26, seed=7):
+    """Drive the reference task code through T post-physics evaluations on synthetic read-back states."""
+    from omni.isaac.core.utils.torch.rotations import quat_conjugate, quat_mul
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    t = make_task(kind, N)
+    robot = t.robot_locomotion if kind == "loco" else t.robot_manipulation
+    init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
+    rec = {k: [] for k in ("readback", "actions", "goal_rand", "obs", "states", "rew", "reset_buf", "goal_reset_buf",
+                           "successes", "consecutive_successes", "progress_buf", "last_actions", "last_base_tip",
+                           "goal_quaternions", "extras", "success_rate", "num_successes", "num_resets", "joint_reset")}
+    extras_keys = None
+    for step in range(T):
+        actions = (torch.rand(N, 12, generator=g) * 2 - 1).clamp(-1, 1)
+        # ---- pre_physics_step (resets flagged envs; consumes the global RNG exactly like the reference)
+        ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        goal_rand = torch.zeros(N, 3)
+        if len(ids) > 0:
+            st = torch.get_rng_state()
+            goal_rand[ids] = torch.rand((len(ids), 3))
+            torch.set_rng_state(st)
+        t.pre_physics_step(actions)
+        # ---- synthetic read-back state, spread across the thresholds of Appendix D
+        q = init_q.repeat(N, 1) + 0.25 * torch.randn(N, 12, generator=g)
+        q[0:4, 5] = q[0:4, 4] - torch.tensor([0.40, 0.39, 2.55, 2.62])        # |dof3-dof2| around penalty/reset windows
+        q[4:8, 0] = torch.tensor([-2.40, -2.45, 0.80, 0.90])                  # a1 dof1 windows
+        q[8:12, 1] = torch.tensor([2.40, 2.45, -0.80, -0.90])                 # a2 dof1 mirrored windows
+        qd = 2.0 * torch.randn(N, 12, generator=g)
+        acc = 20.0 * torch.randn(N, 12, generator=g)
+        pos = torch.cat((0.05 * torch.randn(N, 2, generator=g), 0.13 + 0.02 * torch.randn(N, 1, generator=g)), dim=-1)
+        quat = _rand_unit_quat(g, N, small=0.25)
+        pos[12, 2] = 0.049; pos[13, 2] = 0.051                                  # base height threshold
+        quat[14] = torch.tensor([0.0, 1.0, 0.0, 0.0])                           # upside down -> ground above robot
+        lin = 0.3 * torch.randn(N, 3, generator=g); ang = 1.0 * torch.randn(N, 3, generator=g)
+        tips = 0.15 * torch.randn(N, 4, 3, generator=g)
+        knees = torch.cat((0.15 * torch.randn(N, 8, 2, generator=g), 0.10 + 0.03 * torch.randn(N, 8, 1, generator=g)), dim=-1)
+        knees[15, 3, 2] = 0.0399; knees[16, 3, 2] = 0.0401
+        if kind == "mani":
+            # plate near its rest pose above the inverted robot: world z ~ 0.13, flipped about x
+            flip = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(N, 1)
+            quat = quat_mul(_rand_unit_quat(g, N, small=0.2), flip)
+            pos[12, 2] = 0.051; pos[13, 2] = 0.049
+            quat[14] = torch.tensor([1.0, 0.05, 0.02, 0.01])   # un-flipped plate (exact w=0 in the robot frame is sign-ambiguous in scipy)
+            pos[17, 2] = -0.01                                                  # plate below the robot base
+            knees = torch.cat((0.15 * torch.randn(N, 8, 2, generator=g), 0.03 + 0.03 * torch.randn(N, 8, 1, generator=g)), dim=-1)
+        # envs 20..27 track their goal for the whole sequence -> consecutive-success path + 600 bonus + goal reset
+        track = torch.arange(20, 28)
+        goal = t.goal_quaternions[track]
+        small = _rand_unit_quat(g, len(track), small=0.02)
+        if kind == "loco":
+            quat[track] = quat_conjugate(quat_mul(small, goal))         # conj(bq) (x) conj(goal) ~ identity
+        else:
+            flip = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(len(track), 1)
+            quat[track] = quat_mul(flip, quat_mul(small, goal))         # conj(q_r) (x) pq = small (x) goal
+        quat = quat / quat.norm(dim=-1, keepdim=True)
+        pos[track] = torch.tensor([0.0, 0.0, 0.13]); q[track] = init_q
+        knees[track, :, 2] = 0.1 if kind == "loco" else 0.02
+        robot.joint_positions, robot.joint_velocities, robot.joint_accelerations = q, qd, acc
+        robot.tip_positions, robot.knee_positions = tips, knees
+        if kind == "loco":
+            robot.base_positions, robot.base_quaternions = pos, quat
+            robot.base_linear_velocities, robot.base_angular_velocities = lin, ang
+        else:
+            t.obj.pos, t.obj.quat, t.obj.lin, t.obj.ang = pos, quat, lin, ang
+        # ---- post_physics_step (rl_task.py:240-260)
+        t.progress_buf[:] += 1
+        t.get_observations(); t.calculate_metrics(); t.is_done()
+        rb = torch.cat((q, qd, acc, pos, quat, lin, ang, tips.reshape(N, 12), knees.reshape(N, 24), torch.zeros(N, 2)), dim=-1)
+        if extras_keys is None:
+            extras_keys = sorted(t.extras.keys())
+        rec["readback"].append(rb); rec["actions"].append(actions); rec["goal_rand"].append(goal_rand)
+        rec["obs"].append(t.obs_buf.clone()); rec["states"].append(t.states_buf.clone()); rec["rew"].append(t.rew_buf.clone())
+        rec["reset_buf"].append(t.reset_buf.clone()); rec["goal_reset_buf"].append(t.goal_reset_buf.clone())
+        rec["successes"].append(t.successes.clone()); rec["consecutive_successes"].append(t.consecutive_successes.clone())
+        rec["progress_buf"].append(t.progress_buf.clone()); rec["last_actions"].append(t.last_actions.clone())
+        rec["last_base_tip"].append(t.last_base_tip_positions.reshape(N, 12).clone())
+        rec["goal_quaternions"].append(t.goal_quaternions.clone())
+        rec["extras"].append(torch.stack([torch.as_tensor(t.extras[k], dtype=torch.float32) for k in extras_keys]))
+        rec["success_rate"].append(torch.as_tensor(t.success_rate, dtype=torch.float32).clone())
+        rec["num_successes"].append(t.num_successes.clone()); rec["num_resets"].append(t.num_resets.clone())
+        rec["joint_reset"].append((t.joint1_pos_reset + t.joint23_pos_reset).clone())
+    out = {k: torch.stack(v).numpy() for k, v in rec.items()}
+    out["extras_keys"] = np.array(extras_keys)
+    return out
+
+
+def gen_math(seed=3, N=64):
+    from utils.math import (inverse_rotate_orientations, inverse_transform_vectors, rand_quaternions,
+                            rotate_orientations, transform_vectors)
+    g = torch.Generator().manual_seed(seed)
+    q = _rand_unit_quat(g, N); r = _rand_unit_quat(g, N)
+    t = torch.randn(N, 3, generator=g); V = torch.randn(N, 5, 3, generator=g)
+    torch.manual_seed(seed)
+    st = torch.get_rng_state(); u = torch.rand((N, 3)); torch.set_rng_state(st)
+    rq = rand_quaternions(N, -0.4, 0.4, -0.4, 0.4, -1.57, 1.57, "cpu")
+    out = dict(q=q, r=r, t=t, V=V, transform=transform_vectors(q, t, V, "cpu"),
+               inverse_transform=inverse_transform_vectors(q, t, V, "cpu"),
+               rotate=rotate_orientations(r, q, "cpu"), inverse_rotate=inverse_rotate_orientations(r, q, "cpu"),
+               rand_u=u, rand_quat=rq)
+    # the reference's only self-check input (utils/math.py:212-216)
+    out["selfcheck"] = inverse_rotate_orientations(torch.tensor([-0.5, -0.5, 0.5, 0.5]).repeat(2, 1),
+                                                   torch.tensor([0.7071, 0, 0, 0.7071]).repeat(2, 1))
+    return {k: v.numpy() for k, v in out.items()}
+
+
+def gen_take_action(seed=5, N=8):
+    """RobotOmni.take_action scaling for the three control modes (robot/base/robot.py:444-461)."""
+    from robot.base.robot import RobotOmni
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(N, 12, generator=g) * 2 - 1
+    out = {"actions": a.numpy()}
+
+    class Arti:
+        num_dof = 20
+
+        def set_joint_position_targets(self, x, joint_indices=None):
+            self.got = x
+
+        set_joint_velocity_targets = set_joint_position_targets
+
+        def set_joint_efforts(self, x):
+            self.got = x
+
+    for mode in ("position", "velocity", "effort"):
+        r = object.__new__(RobotOmni)
+        r.num_envs, r.device = N, "cpu"
+        r.robot_description = types.SimpleNamespace(control_mode=mode)
+        r._robot_articulation = Arti()
+        r._omni_dof_indices = torch.arange(12)
+        r._positions_upper = torch.tensor([np.pi], dtype=torch.float32).repeat(1, 12); r._positions_lower = -r._positions_upper
+        r._velocity_upper = torch.full((12,), 3.0); r._velocity_lower = -r._velocity_upper
+        r._torque_upper = torch.full((12,), 1.5); r._torque_lower = -r._torque_upper
+        r.take_action(a.clone())
+        out[mode] = r._robot_articulation.got.numpy()
+    return out
+
+
+def main():
+    assert os.path.isdir(REF_RL), "reference tree not present: golden vectors can only be regenerated in the build container"
+    _install_placeholders()
+    sys.path[:0] = [REF_RL, os.path.dirname(REF_RL)]
+    os.makedirs(OUT, exist_ok=True)
+    for kind in ("loco", "mani"):
+        d = gen_task(kind)
+        np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
+        print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "states", "rew", "extras")},
+              "resets/step", d["reset_buf"].sum(1)[:8], "max consec", d["consecutive_successes"].max(),
+              "bonus steps", int((d["rew"] > 300).sum()))
+    np.savez_compressed(os.path.join(OUT, "math.npz"), **gen_math())
+    np.savez_compressed(os.path.join(OUT, "take_action.npz"), **gen_take_action())
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
