@@ -1,0 +1,130 @@
+/*
+ * lm_engine.h -- C ABI of the MI355X loco-manipulation physics-step engine (liblm_engine.so).
+ *
+ * The reference has no FFI on this path: the boundary is the Python object protocol
+ *   VecEnvRLGames.step / reset / set_task      RobotLearning/omniisaacgymenvs/envs/vec_env_rlgames.py:48-90
+ *   RLTask buffers + post_physics_step         RobotLearning/omniisaacgymenvs/tasks/base/rl_task.py:104-113,240-260
+ * below which it calls closed-source PhysX (World.step, ArticulationView / RigidPrimView tensor API,
+ * vec_env_rlgames.py:65; robot/base/robot.py:276-321,357-461; objects/base/rigid_object.py:30-58).
+ * These entry points are what a binding for that path binds instead (INTEGRATION.md shows the ctypes
+ * stub).  Plain pointers and sizes only; no torch types; no exceptions cross the ABI; every call
+ * returns 0 on success or a negative LM_E* code (lm_last_error() gives the text).
+ *
+ * Memory: all device buffers are owned by the handle (hipMalloc) and exposed through lm_ptr();
+ * output buffers for step() are caller-provided device pointers (so a host binding can hand out
+ * fresh tensors per step, matching the "returned tensors are clones" contract of
+ * vec_env_rlgames.py:41-46 without extra copy kernels).  The stream is the caller's.
+ */
+#ifndef LM_ENGINE_H
+#define LM_ENGINE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_OK 0
+#define LM_EINVAL (-1)
+#define LM_EHIP (-2)
+#define LM_ENOMEM (-3)
+
+#define LM_MODE_LOCO 0   /* free base on a ground plane   (QuadrupedPoseControl)      */
+#define LM_MODE_MANI 1   /* fixed inverted base + plate    (QuadrupedManipulatePlate)  */
+
+#define LM_STATE_ROWS 90   /* float state, SoA [row][N]: see DESIGN.md 4.1 */
+#define LM_CNT_ROWS 6      /* int64 counters, SoA [row][N] */
+#define LM_NUM_OBS 64
+#define LM_NUM_STATES 93
+#define LM_NUM_ACTIONS 12
+#define LM_NUM_EXTRAS 8
+#define LM_TABLE_FLOATS 486  /* 10 hub + 4 x 119 limb (RobotModel.packed_table) */
+
+/* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
+ * sources in the reference are cited there. */
+typedef struct lm_params {
+  float dt, kd, tau_max, act_scale, mu, tip_radius, baumgarte, max_depen_vel, gravity;
+  int32_t substeps, pgs_iters, mode;
+  float fixed_base_pos[3], fixed_base_quat[4];
+  float plate_mass, plate_com[3], plate_inertia[3], plate_half[3], plate_center[3];
+  float init_q[12], init_base_pos[3], init_base_quat[4], init_plate_pos[3], init_plate_quat[4];
+  float default_tip[12], goal_lo[3], goal_hi[3];
+  float s_pos, s_lin, s_ang, s_q, s_qd;
+  float quat_scale, rot_eps, trans_scale, acc_scale, rate_scale, bonus, limit_pen, fall_pen, succ_thresh;
+  int32_t max_consec, max_episode;
+  float d23_pen[2], d23_rst[2], d1_pen[4][2], d1_rst[4][2];
+  float h_base, h_corner, h_knee, corner[4][3];
+  float clip_obs, clip_actions;
+  int32_t max_reset_counts;
+  /* derived by lm_create (callers leave zero) */
+  float plate_si[10];      /* plate spatial inertia about its origin */
+  float plate_phi[36];     /* its inverse */
+  float ctrl_dt_inv;
+} lm_params;
+
+typedef struct lm_engine lm_engine;   /* opaque */
+
+/* Pointers the host side may wrap zero-copy. */
+typedef enum {
+  LM_PTR_STATE = 0,     /* float [LM_STATE_ROWS][N]                                  */
+  LM_PTR_CNT = 1,       /* int64 [LM_CNT_ROWS][N]: successes, consecutive_successes,
+                           goal_reset_buf, reset_buf, progress_buf, episode_count    */
+  LM_PTR_OBS_BUF = 2,   /* float [N][64]  task.obs_buf (unclipped)   rl_task.py:107  */
+  LM_PTR_STATES_BUF = 3,/* float [N][93]  task.states_buf                            */
+  LM_PTR_REW_BUF = 4,   /* float [N]      task.rew_buf                               */
+  LM_PTR_EXTRAS = 5,    /* float [8]      reward-term means + success_rate           */
+  LM_PTR_STATS = 6,     /* int64 [2] num_successes, num_resets ; then float success_rate at byte 16 */
+  LM_PTR_TERMS = 7      /* float [8][N]   per-env reward terms of the last step      */
+} lm_ptr_kind;
+
+/* Create an engine for n_envs environments on the current HIP device.
+ *   table      : LM_TABLE_FLOATS packed robot model (host pointer)
+ *   params     : n_tasks (1 or 2) parameter blocks (host pointer); with 2 tasks, envs [0, split_env)
+ *                use params[0] and [split_env, n_envs) use params[1] (co-train layout,
+ *                joint_locomanipulation.py:25-34); split_env must be a multiple of 16.
+ *   seed       : stream seed of the in-kernel goal sampler (replaces torch.rand in utils/math.py:184)
+ * All envs start with reset_buf = 1 (rl_task.py:111). */
+int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks,
+              int split_env, uint32_t seed);
+int lm_destroy(lm_engine* h);
+
+/* One VecEnvRLGames.step(): reset flagged envs, clamp + apply actions, controlFrequencyInv physics
+ * sub-steps, observations / reward / termination.  (vec_env_rlgames.py:56-79)
+ *   actions     device float [N][12]
+ *   goal_rand   device float [N][3] uniforms for goal sampling, or NULL for the in-kernel hash RNG
+ *   out_*       device buffers receiving clipped copies for the caller (any may be NULL):
+ *               obs [N][64], states [N][93], rew [N], resets int64 [N], extras float [8]
+ *   stream      hipStream_t (void* here so the header needs no HIP include) */
+int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states,
+            float* out_rew, int64_t* out_resets, float* out_extras, void* stream);
+
+/* RLTask.reset(): flag every env for reset (rl_task.py:227-230). */
+int lm_reset_all(lm_engine* h, void* stream);
+
+/* Task layer alone on explicit read-back inputs (device float [N][87], layout of oracle LMO_READBACK);
+ * uses and updates the handle's task state / counters exactly like the tail of lm_step.
+ * Test entry point for the golden vectors captured from the reference's Python. */
+int lm_task_eval(lm_engine* h, const float* readback, const float* actions, float* out_obs, float* out_states,
+                 float* out_rew, int64_t* out_resets, float* out_extras, void* stream);
+
+/* Only the reset scatter of lm_step (reset_idx, quadruped_pose_control.py:230-299). */
+int lm_apply_resets(lm_engine* h, const float* goal_rand, void* stream);
+
+/* n physics sub-steps with given joint-velocity targets (device float [N][12]); no task layer. */
+int lm_substeps(lm_engine* h, const float* targets, int n, void* stream);
+
+/* World tip (device float [N][4][3]) and knee ([N][8][3]) positions of the current state. */
+int lm_forward_kinematics(lm_engine* h, float* tips, float* knees, void* stream);
+
+/* Debug: dense mass matrix [N][18][18] and bias [N][18] assembled from the limb-aggregate terms. */
+int lm_debug_dynamics(lm_engine* h, float* M, float* hvec, void* stream);
+
+void* lm_ptr(lm_engine* h, int kind);
+int lm_num_envs(const lm_engine* h);
+int lm_set_seed(lm_engine* h, uint32_t seed);
+const char* lm_last_error(void);
+const char* lm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1016 @@
+// lm_engine.hip -- MI355X (gfx950) physics-step engine: kernels + C ABI (include/lm_engine.h).
+//
+// Mapping: one 64-lane wavefront = 16 environments x 4 limbs ("limb per lane").  Each lane runs the
+// limb-aggregate articulated-body sweep for its overconstrained module (5 bodies, one embedded
+// Bennett loop, 3 independent joints); the four lanes of an env meet at the hub through DPP
+// quad-permute reductions (backward sweep: articulated inertia + bias onto the hub; forward sweep:
+// hub acceleration back to the limbs).  State is SoA [row][N] in HBM, the robot table sits in LDS,
+// per-task constants are read through scalar loads.  DESIGN.md sections 3-5 derive every formula.
+//
+// Reference rows replaced: a4-a6 (reset scatter + action scaling), a7 (PhysX world.step x
+// controlFrequencyInv), a8 (state read-back), a9-a11 (obs / reward / termination), a13 (plate deltas).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <new>
+#include "lm_math.h"
+#include "../../include/lm_engine.h"
+
+#define HUB_FLOATS 10
+#define LIMB_STRIDE 119
+#define ENVS_PER_WAVE 16
+#define NPART 12           // per-block partial sums: 7 reward terms, goal_reset, reset, pad
+
+// state rows
+#define R_FB0 0            // base: pos 0..2 quat 3..6 lin 7..9 ang 10..12
+#define R_Q 13
+#define R_QD 25
+#define R_FB1 37           // plate: pos, quat, lin, ang
+#define R_LACT 50
+#define R_LQD 62
+#define R_LTIP 74
+#define R_GOAL 86
+
+#define SQRT2F 1.41421356237f
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", #x, hipGetErrorString(e_)); return LM_EHIP; } } while (0)
+
+struct lm_engine {
+  int N, n_tasks, split, nblocks;
+  uint32_t seed;
+  lm_params* d_params;     // [2]
+  float* d_table;
+  float* d_state; int64_t* d_cnt;
+  float *d_obs, *d_states, *d_rew, *d_extras, *d_terms, *d_partials;
+  char* d_stats;           // int64 num_successes, int64 num_resets, float success_rate
+  lm_params h_params[2];
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+LM_DEV uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+LM_DEV void hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, float* u) {
+  uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(episode * 0x85EBCA6BU + 0x165667B1U));
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) { uint32_t r = mix32(base + (k + 1U) * 0xC2B2AE35U); u[k] = (float)(r >> 8) * (1.0f / 16777216.0f); }
+}
+LM_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
+  float sy, cy, sr, cr, sp, cp;
+  sincosf(yaw * 0.5f, &sy, &cy); sincosf(roll * 0.5f, &sr, &cr); sincosf(pitch * 0.5f, &sp, &cp);
+  Q4 q; q.w = cy * cr * cp + sy * sr * sp; q.x = cy * sr * cp - sy * cr * sp; q.y = cy * cr * sp + sy * sr * cp; q.z = sy * cr * cp - cy * sr * sp;
+  return q;
+}
+LM_DEV M3 load_m3_rowmajor(const float* t) {
+  M3 R; R.c0 = v3(t[0], t[3], t[6]); R.c1 = v3(t[1], t[4], t[7]); R.c2 = v3(t[2], t[5], t[8]); return R;
+}
+// hub body: table holds (m, com, I about COM) in the hub frame -> spatial inertia about the hub origin
+LM_DEV SI hub_inertia(const float* t) {
+  M3 I; I.c0 = v3(1, 0, 0); I.c1 = v3(0, 1, 0); I.c2 = v3(0, 0, 1);
+  return place_inertia(t, I, v3(0, 0, 0));
+}
+LM_DEV SI load_si(const float* t) { SI I; I.m = t[0]; I.h = v3(t[1], t[2], t[3]); I.xx = t[4]; I.yy = t[5]; I.zz = t[6]; I.xy = t[7]; I.xz = t[8]; I.yz = t[9]; return I; }
+LM_DEV void si_to_66(const SI& I, float A[6][6]) {
+  A[0][0] = I.xx; A[0][1] = I.xy; A[0][2] = I.xz; A[1][1] = I.yy; A[1][2] = I.yz; A[2][2] = I.zz;
+  A[1][0] = I.xy; A[2][0] = I.xz; A[2][1] = I.yz;
+  // M_wv = [h]x, M_vw = -[h]x
+  A[0][3] = 0.f;     A[0][4] = -I.h.z; A[0][5] = I.h.y;
+  A[1][3] = I.h.z;   A[1][4] = 0.f;    A[1][5] = -I.h.x;
+  A[2][3] = -I.h.y;  A[2][4] = I.h.x;  A[2][5] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { A[3 + i][j] = A[j][3 + i]; A[3 + i][3 + j] = (i == j) ? I.m : 0.f; }
+}
+LM_DEV void sv_to_arr(SV a, float* o) { o[0] = a.w.x; o[1] = a.w.y; o[2] = a.w.z; o[3] = a.v.x; o[4] = a.v.y; o[5] = a.v.z; }
+LM_DEV SV arr_to_sv(const float* o) { return sv(v3(o[0], o[1], o[2]), v3(o[3], o[4], o[5])); }
+
+// one joint of the limb tree: parent pose (Rp, op) + table entry (R 9 row-major, p 3, sign) + rotation (c, s)
+LM_DEV void joint_frame(const M3& Rp, V3 op, const float* tj, float c, float s, M3& R, V3& o, V3& z) {
+  M3 A = mul(Rp, load_m3_rowmajor(tj));
+  float sg = tj[12]; float ss = sg * s;
+  R.c0 = fma3(c, A.c0, ss * A.c1);
+  R.c1 = fma3(c, A.c1, (-ss) * A.c0);
+  R.c2 = A.c2;
+  o = op + mul(Rp, v3(tj[9], tj[10], tj[11]));
+  z = sg * A.c2;
+}
+
+// kinematics + dynamics terms of one limb, all in hub ("base") coordinates about the hub origin
+struct LimbKin {
+  M3 R3; V3 os, o4, o3, o1, o2;            // frames needed later (tip on link3, knees = o3, o2)
+  SV s1, s2, sp1, s3, sp2;                 // joint axes
+  float g1, pd, pdd;                       // closure: dp/dD, passive rate, passive vp-acceleration
+  M3 Rs, R4, R1, R2;
+};
+
+LM_DEV void limb_kinematics(const float* tl, const float q[3], const float qd[3], LimbKin& K) {
+  float s1_, c1_, s2_, c2_, s3_, c3_;
+  sincosf(q[0], &s1_, &c1_); sincosf(q[1], &s2_, &c2_); sincosf(q[2], &s3_, &c3_);
+  float cD = c2_ * c3_ + s2_ * s3_, sD = s2_ * c3_ - c2_ * s3_;      // D = q2 - q3
+  float inv = 1.0f / (3.0f - cD);
+  float cp = (3.0f * cD - 1.0f) * inv, sp = 2.0f * SQRT2F * sD * inv;
+  K.g1 = 2.0f * SQRT2F * inv;
+  float g2 = -2.0f * SQRT2F * sD * inv * inv;
+  float dd = qd[1] - qd[2];
+  K.pd = K.g1 * dd; K.pdd = g2 * dd * dd;
+  M3 I3; I3.c0 = v3(1, 0, 0); I3.c1 = v3(0, 1, 0); I3.c2 = v3(0, 0, 1);
+  V3 z1, z2, zp1, z3, zp2;
+  joint_frame(I3, v3(0, 0, 0), tl + 0, c1_, s1_, K.Rs, K.os, z1);
+  joint_frame(K.Rs, K.os, tl + 13, c2_, s2_, K.R4, K.o4, z2);
+  joint_frame(K.R4, K.o4, tl + 26, cp, sp, K.R3, K.o3, zp1);          // p1 = +g(D)
+  joint_frame(K.Rs, K.os, tl + 39, c3_, s3_, K.R1, K.o1, z3);
+  joint_frame(K.R1, K.o1, tl + 52, cp, -sp, K.R2, K.o2, zp2);         // p2 = -g(D)
+  K.s1 = axis_sv(z1, K.os); K.s2 = axis_sv(z2, K.o4); K.sp1 = axis_sv(zp1, K.o3);
+  K.s3 = axis_sv(z3, K.o1); K.sp2 = axis_sv(zp2, K.o2);
+}
+
+struct LimbDyn {
+  SV Fq0, Fq1, Fq2;       // coupling columns (6x3): hub wrench per unit limb acceleration
+  float H[6];             // limb joint-space inertia, packed [00,01,02,11,12,22]
+  float hq[3];            // limb bias
+  SV fcs;                 // limb bias wrench on the hub
+  SI Isc;                 // limb composite inertia
+  SV j31, j32;            // motion of link3 per unit rate of (q2, q3); per unit q1 it is s1
+  V3 x;                   // tip point (hub coords)
+};
+
+LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], SV v0, SV avp0, LimbDyn& D) {
+  SI Is = place_inertia(tl + 65, K.Rs, K.os), I4 = place_inertia(tl + 75, K.R4, K.o4), I3 = place_inertia(tl + 85, K.R3, K.o3);
+  SI I1 = place_inertia(tl + 95, K.R1, K.o1), I2 = place_inertia(tl + 105, K.R2, K.o2);
+  SV j1 = qd[0] * K.s1, j2 = qd[1] * K.s2, jp1 = K.pd * K.sp1, j3 = qd[2] * K.s3, jp2 = (-K.pd) * K.sp2;
+  SV vs = v0 + j1, v4 = vs + j2, v3_ = v4 + jp1, v1 = vs + j3, v2 = v1 + jp2;
+  SV as = avp0 + mcross(v0, j1);
+  SV a4 = as + mcross(vs, j2);
+  SV a3 = fma6(K.pdd, K.sp1, a4 + mcross(v4, jp1));
+  SV a1 = as + mcross(vs, j3);
+  SV a2 = fma6(-K.pdd, K.sp2, a1 + mcross(v1, jp2));
+  SV ps = Is * as + fcross(vs, Is * vs);
+  SV p4 = I4 * a4 + fcross(v4, I4 * v4);
+  SV p3 = I3 * a3 + fcross(v3_, I3 * v3_);
+  SV p1 = I1 * a1 + fcross(v1, I1 * v1);
+  SV p2 = I2 * a2 + fcross(v2, I2 * v2);
+  SV fc4 = p4 + p3, fc1 = p1 + p2;
+  D.fcs = ps + fc4 + fc1;
+  float h1 = sdot(K.s1, D.fcs), h2 = sdot(K.s2, fc4), hp1 = sdot(K.sp1, p3), h3 = sdot(K.s3, fc1), hp2 = sdot(K.sp2, p2);
+  float g1 = K.g1;
+  D.hq[0] = h1; D.hq[1] = h2 + g1 * (hp1 - hp2); D.hq[2] = h3 - g1 * (hp1 - hp2);
+  SI I4c = I4 + I3, I1c = I1 + I2;
+  D.Isc = Is + I4c + I1c;
+  SV F1 = D.Isc * K.s1, F2 = I4c * K.s2, Fp1 = I3 * K.sp1, F3 = I1c * K.s3, Fp2 = I2 * K.sp2;
+  SV dF = Fp1 - Fp2;
+  D.Fq0 = F1; D.Fq1 = fma6(g1, dF, F2); D.Fq2 = fma6(-g1, dF, F3);
+  float H11 = sdot(K.s1, F1), H12 = sdot(K.s1, F2), H1p1 = sdot(K.s1, Fp1), H13 = sdot(K.s1, F3), H1p2 = sdot(K.s1, Fp2);
+  float H22 = sdot(K.s2, F2), H2p1 = sdot(K.s2, Fp1), Hp1p1 = sdot(K.sp1, Fp1);
+  float H33 = sdot(K.s3, F3), H3p2 = sdot(K.s3, Fp2), Hp2p2 = sdot(K.sp2, Fp2);
+  float gg = g1 * g1 * (Hp1p1 + Hp2p2);
+  D.H[0] = H11; D.H[1] = H12 + g1 * (H1p1 - H1p2); D.H[2] = H13 - g1 * (H1p1 - H1p2);
+  D.H[3] = H22 + 2.0f * g1 * H2p1 + gg; D.H[4] = -g1 * (H2p1 + H3p2) - gg; D.H[5] = H33 + 2.0f * g1 * H3p2 + gg;
+  D.j31 = fma6(g1, K.sp1, K.s2); D.j32 = (-g1) * K.sp1;
+  D.x = K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117]));
+}
+
+// projected Gauss-Seidel over the 4 tip contacts of one env; lanes take turns (limb 0..3), the hub/plate
+// velocity change w is kept identical in the 4 lanes.
+template <int K>
+LM_DEV void pgs_turn(int limb, float mu, float bn, const float vf[3], const float Wl[6], const float rW[3],
+                     const SV T[3], const SV B[3], float lam[3], SV& w) {
+  SV wl = w;
+  float v = vf[0] + bn + Wl[0] * lam[0] + Wl[1] * lam[1] + Wl[2] * lam[2] + sdot(T[0], wl);
+  float ln = fmaxf(0.0f, lam[0] - v * rW[0]);
+  wl = fma6(ln - lam[0], B[0], wl);
+  float lim = mu * ln;
+  v = vf[1] + Wl[1] * ln + Wl[3] * lam[1] + Wl[4] * lam[2] + sdot(T[1], wl);
+  float l1 = fminf(lim, fmaxf(-lim, lam[1] - v * rW[1]));
+  wl = fma6(l1 - lam[1], B[1], wl);
+  v = vf[2] + Wl[2] * ln + Wl[4] * l1 + Wl[5] * lam[2] + sdot(T[2], wl);
+  float l2 = fminf(lim, fmaxf(-lim, lam[2] - v * rW[2]));
+  wl = fma6(l2 - lam[2], B[2], wl);
+  SV dw = wl - w;
+  w.w.x += quad_bcast<K>(dw.w.x); w.w.y += quad_bcast<K>(dw.w.y); w.w.z += quad_bcast<K>(dw.w.z);
+  w.v.x += quad_bcast<K>(dw.v.x); w.v.y += quad_bcast<K>(dw.v.y); w.v.z += quad_bcast<K>(dw.v.z);
+  bool mine = (limb == K);
+  lam[0] = mine ? ln : lam[0]; lam[1] = mine ? l1 : lam[1]; lam[2] = mine ? l2 : lam[2];
+}
+
+LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3], const float Wl[6],
+                      const SV T[3], const SV B[3], float lam[3], SV& w) {
+  // full Delassus diagonal = limb-local part + hub/plate part T_r^T Phi T_r
+  float rW[3] = {1.0f / (Wl[0] + sdot(T[0], B[0])), 1.0f / (Wl[3] + sdot(T[1], B[1])), 1.0f / (Wl[5] + sdot(T[2], B[2]))};
+  lam[0] = lam[1] = lam[2] = 0.f; w = sv(v3(0, 0, 0), v3(0, 0, 0));
+  for (int it = 0; it < iters; it++) {
+    pgs_turn<0>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
+    pgs_turn<1>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
+    pgs_turn<2>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
+    pgs_turn<3>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
+  }
+}
+
+// free rigid body carried as (position, quaternion, body-coordinate spatial velocity about its origin)
+struct FreeBody { V3 p; Q4 q; SV u; };
+
+LM_DEV void integrate_free(FreeBody& F, const M3& R, float dt) {
+  V3 ww = mul(R, F.u.w);
+  float wn = sqrtf(dot(ww, ww)), th = wn * dt;
+  Q4 dq;
+  if (th < 1e-8f) { dq.w = 1.f; dq.x = 0.5f * dt * ww.x; dq.y = 0.5f * dt * ww.y; dq.z = 0.5f * dt * ww.z; }
+  else { float sh, ch; sincosf(0.5f * th, &sh, &ch); float s = sh / wn; dq.w = ch; dq.x = s * ww.x; dq.y = s * ww.y; dq.z = s * ww.z; }
+  Q4 qn = qmul(dq, F.q);
+  float rn = rsqrtf(qn.w * qn.w + qn.x * qn.x + qn.y * qn.y + qn.z * qn.z);
+  F.q.w = qn.w * rn; F.q.x = qn.x * rn; F.q.y = qn.y * rn; F.q.z = qn.z * rn;
+  M3 Rn = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
+  F.p = fma3(dt, mul(Rn, F.u.v), F.p);
+}
+
+// One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
+// robot base is fixed at (Rb, pb).
+template <int MODE>
+LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb,
+                    FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3]) {
+  const float dt = P->dt, kd = P->kd, tmax = P->tau_max;
+  M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
+  M3 Rb; V3 pb; SV v0;
+  if (MODE == 0) { Rb = Rf; pb = F.p; v0 = F.u; } else { Rb = Rfix; pb = pfix; v0 = sv(v3(0, 0, 0), v3(0, 0, 0)); }
+  SV avp0 = sv(v3(0, 0, 0), P->gravity * row2(Rb));      // fictitious upward acceleration = gravity
+  LimbKin K; limb_kinematics(tl, q, qd, K);
+  LimbDyn D; limb_dynamics(tl, K, qd, v0, avp0, D);
+
+  // ---- contact geometry of this limb's tip
+  V3 C0, C1, C2;        // contact axes (n, t1, t2) in hub coordinates
+  float bn;             // normal-row bias
+  SV Tp[3];             // MODE 1: T rows (plate side), MODE 0 filled later
+  SV up_free;           // MODE 1: plate free velocity
+  float phi;
+  if (MODE == 0) {
+    C0 = row2(Rb); C1 = row0(Rb); C2 = row1(Rb);
+    phi = pb.z + dot(C0, D.x) - P->tip_radius;
+  } else {
+    V3 xw = pb + mul(Rb, D.x);
+    V3 y0 = mulT(Rf, xw - F.p);
+    V3 y = y0 - v3(P->plate_center[0], P->plate_center[1], P->plate_center[2]);
+    float sg = (y.z >= 0.f) ? 1.f : -1.f;
+    phi = sg * y.z - P->plate_half[2] - P->tip_radius;
+    if (fabsf(y.x) > P->plate_half[0] || fabsf(y.y) > P->plate_half[1]) phi = 1.0e3f;
+    // contact axes in plate coords: n=(0,0,sg) t1=(1,0,0) t2=(0,sg,0); in hub coords: Rb^T Rf axis
+    M3 Mrp = mulTA(Rb, Rf);
+    C0 = sg * Mrp.c2; C1 = Mrp.c0; C2 = sg * Mrp.c1;
+    V3 a0 = v3(0, 0, sg), a1 = v3(1, 0, 0), a2 = v3(0, sg, 0);
+    Tp[0] = sv(-cross(y0, a0), -a0); Tp[1] = sv(-cross(y0, a1), -a1); Tp[2] = sv(-cross(y0, a2), -a2);
+    // plate free motion
+    SI Ip = load_si(P->plate_si);
+    SV hp = fcross(F.u, Ip * F.u);
+    V3 fg = (-P->plate_mass * P->gravity) * row2(Rf);
+    V3 c = v3(P->plate_com[0], P->plate_com[1], P->plate_com[2]);
+    hp = hp - sv(cross(c, fg), fg);
+    float Ph[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) Ph[i][j] = P->plate_phi[6 * i + j];
+    up_free = F.u - dt * mul66(Ph, hp);
+  }
+  bn = (phi >= 0.f) ? phi / dt : fmaxf(P->baumgarte * phi / dt, -P->max_depen_vel);
+  // tip linear velocity per unit generalized rate, contact coordinates
+  V3 e0 = K.s1.v + cross(K.s1.w, D.x);
+  V3 e1 = D.j31.v + cross(D.j31.w, D.x);
+  V3 e2 = D.j32.v + cross(D.j32.w, D.x);
+  float Jq[3][3] = {{dot(C0, e0), dot(C0, e1), dot(C0, e2)}, {dot(C1, e0), dot(C1, e1), dot(C1, e2)}, {dot(C2, e0), dot(C2, e1), dot(C2, e2)}};
+  SV Jb[3] = {sv(cross(D.x, C0), C0), sv(cross(D.x, C1), C1), sv(cross(D.x, C2), C2)};   // MODE 0 hub rows
+
+  bool sat[3] = {false, false, false}; float tsat[3] = {0.f, 0.f, 0.f};
+  float qdn[3]; SV un;
+  for (int pass = 0; pass < 2; pass++) {
+    float Ha[6] = {D.H[0], D.H[1], D.H[2], D.H[3], D.H[4], D.H[5]}, r[3];
+    const int di[3] = {0, 3, 5};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (!sat[a]) { Ha[di[a]] += dt * kd; r[a] = kd * (tgt[a] - qd[a]) - D.hq[a]; }
+      else r[a] = tsat[a] - D.hq[a];
+    }
+    float Hi[6]; inv3sym(Ha, Hi);
+    // K = Fq Hinv  (columns)
+    SV K0 = fma6(Hi[0], D.Fq0, fma6(Hi[1], D.Fq1, Hi[2] * D.Fq2));
+    SV K1 = fma6(Hi[1], D.Fq0, fma6(Hi[3], D.Fq1, Hi[4] * D.Fq2));
+    SV K2 = fma6(Hi[2], D.Fq0, fma6(Hi[4], D.Fq1, Hi[5] * D.Fq2));
+    float qdd[3], qdf[3]; SV v0f; float Phi[6][6];
+    if (MODE == 0) {
+      float A[6][6]; si_to_66(D.Isc, A);
+      float k0[6], k1[6], k2[6], f0[6], f1[6], f2[6];
+      sv_to_arr(K0, k0); sv_to_arr(K1, k1); sv_to_arr(K2, k2); sv_to_arr(D.Fq0, f0); sv_to_arr(D.Fq1, f1); sv_to_arr(D.Fq2, f2);
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) A[i][j] = quad_sum(A[i][j] - (k0[i] * f0[j] + k1[i] * f1[j] + k2[i] * f2[j]));
+      SV bA = quad_sum(fma6(r[0], K0, fma6(r[1], K1, fma6(r[2], K2, D.fcs))));
+      // hub body itself
+      SI I0 = hub_inertia(th);
+      float A0[6][6]; si_to_66(I0, A0);
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) A[i][j] += A0[i][j];
+      bA = bA + I0 * avp0 + fcross(v0, I0 * v0);
+      inv6spd(A, Phi);
+      SV a0 = mul66(Phi, sv(-bA.w, -bA.v));
+      float t0 = r[0] - sdot(D.Fq0, a0), t1 = r[1] - sdot(D.Fq1, a0), t2 = r[2] - sdot(D.Fq2, a0);
+      qdd[0] = Hi[0] * t0 + Hi[1] * t1 + Hi[2] * t2; qdd[1] = Hi[1] * t0 + Hi[3] * t1 + Hi[4] * t2; qdd[2] = Hi[2] * t0 + Hi[4] * t1 + Hi[5] * t2;
+      v0f = fma6(dt, a0, v0);
+    } else {
+      qdd[0] = Hi[0] * r[0] + Hi[1] * r[1] + Hi[2] * r[2]; qdd[1] = Hi[1] * r[0] + Hi[3] * r[1] + Hi[4] * r[2]; qdd[2] = Hi[2] * r[0] + Hi[4] * r[1] + Hi[5] * r[2];
+      v0f = up_free;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) Phi[i][j] = P->plate_phi[6 * i + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) qdf[a] = fmaf(dt, qdd[a], qd[a]);
+    // contact operator
+    SV T[3], B[3]; float Wl[6], vf[3];
+    float JH[3][3];   // Jq * Hinv
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      JH[rr][0] = Jq[rr][0] * Hi[0] + Jq[rr][1] * Hi[1] + Jq[rr][2] * Hi[2];
+      JH[rr][1] = Jq[rr][0] * Hi[1] + Jq[rr][1] * Hi[3] + Jq[rr][2] * Hi[4];
+      JH[rr][2] = Jq[rr][0] * Hi[2] + Jq[rr][1] * Hi[4] + Jq[rr][2] * Hi[5];
+    }
+    Wl[0] = JH[0][0] * Jq[0][0] + JH[0][1] * Jq[0][1] + JH[0][2] * Jq[0][2];
+    Wl[1] = JH[0][0] * Jq[1][0] + JH[0][1] * Jq[1][1] + JH[0][2] * Jq[1][2];
+    Wl[2] = JH[0][0] * Jq[2][0] + JH[0][1] * Jq[2][1] + JH[0][2] * Jq[2][2];
+    Wl[3] = JH[1][0] * Jq[1][0] + JH[1][1] * Jq[1][1] + JH[1][2] * Jq[1][2];
+    Wl[4] = JH[1][0] * Jq[2][0] + JH[1][1] * Jq[2][1] + JH[1][2] * Jq[2][2];
+    Wl[5] = JH[2][0] * Jq[2][0] + JH[2][1] * Jq[2][1] + JH[2][2] * Jq[2][2];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      if (MODE == 0) {
+        // T = Jb^T - K Jq^T  (hub wrench produced by a unit contact impulse)
+        T[rr] = Jb[rr] - fma6(Jq[rr][0], K0, fma6(Jq[rr][1], K1, Jq[rr][2] * K2));
+        vf[rr] = sdot(Jb[rr], v0f) + Jq[rr][0] * qdf[0] + Jq[rr][1] * qdf[1] + Jq[rr][2] * qdf[2];
+      } else {
+        T[rr] = Tp[rr];
+        vf[rr] = sdot(Tp[rr], v0f) + Jq[rr][0] * qdf[0] + Jq[rr][1] * qdf[1] + Jq[rr][2] * qdf[2];
+      }
+      B[rr] = mul66(Phi, T[rr]);
+    }
+    float lam[3]; SV w;
+    pgs_solve(P->pgs_iters, limb, P->mu, bn, vf, Wl, T, B, lam, w);
+    // apply impulses
+    un = v0f + w;
+#pragma unroll
+    for (int a = 0; a < 3; a++) qdn[a] = qdf[a] + JH[0][a] * lam[0] + JH[1][a] * lam[1] + JH[2][a] * lam[2];
+    if (MODE == 0) { qdn[0] -= sdot(K0, w); qdn[1] -= sdot(K1, w); qdn[2] -= sdot(K2, w); }
+    if (pass == 0) {
+      int any = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        float tau = kd * (tgt[a] - qdn[a]);
+        if (tau > tmax) { sat[a] = true; tsat[a] = tmax; any = 1; }
+        else if (tau < -tmax) { sat[a] = true; tsat[a] = -tmax; any = 1; }
+      }
+      any = quad_sum_i(any);
+      if (!__any(any)) break;                  // wave-uniform: nobody saturated
+      if (any == 0) { sat[0] = sat[1] = sat[2] = false; }
+      // envs without saturation redo the identical unsaturated solve in pass 1 (same result)
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) { qd[a] = qdn[a]; q[a] = fmaf(dt, qdn[a], q[a]); }
+  F.u = un;
+  if (MODE == 0) integrate_free(F, Rb, dt); else integrate_free(F, Rf, dt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// task layer (obs / reward / termination), one env = 4 lanes; restates
+// quadruped_pose_control.py:301-426,428-560,562-633 and quadruped_manipulate_plate.py:311-435,569-652
+// ------------------------------------------------------------------------------------------------
+struct TaskIn {
+  float q[3], qd[3], acc[3], act[3];       // this limb's joints (dof1, dof2, dof3)
+  V3 tipw, knee2, knee3;                   // world positions of this limb's tip and knees
+  V3 fp; Q4 fq; V3 lin, ang;               // free body (base or plate) world pose / velocity
+};
+struct TaskState { float lact[3]; V3 ltip; Q4 goal; int succ, consec, greset, reset, progress; };
+struct TaskOut { float rew; float terms[8]; };
+
+template <int MODE>
+LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const TaskIn& I, TaskState& S, TaskOut& O,
+                      float* sObs, float* sSt) {
+  S.progress += 1;
+  V3 opos, olin, oang; Q4 oq; M3 Rr; V3 pr;
+  if (MODE == 0) {
+    Rr = quat_to_mat(I.fq.w, I.fq.x, I.fq.y, I.fq.z); pr = I.fp;
+    opos = mulT(Rr, -I.fp); oq = qconj(I.fq); olin = mulT(Rr, -I.lin); oang = mulT(Rr, -I.ang);
+  } else {
+    Q4 qr; qr.w = P->fixed_base_quat[0]; qr.x = P->fixed_base_quat[1]; qr.y = P->fixed_base_quat[2]; qr.z = P->fixed_base_quat[3];
+    Rr = quat_to_mat(qr.w, qr.x, qr.y, qr.z); pr = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
+    opos = mulT(Rr, I.fp - pr);
+    oq = qmul(qconj(qr), I.fq);
+    if (oq.w < 0.f) { oq.w = -oq.w; oq.x = -oq.x; oq.y = -oq.y; oq.z = -oq.z; }
+    olin = mulT(Rr, I.lin); oang = mulT(Rr, I.ang);
+  }
+  V3 btip = mulT(Rr, I.tipw - pr);
+  Q4 qd_ = qmul(oq, qconj(S.goal));
+  float fl = (qd_.w < 0.f) ? -1.f : 1.f;
+  Q4 qf; qf.w = fl * qd_.w; qf.x = fl * qd_.x; qf.y = fl * qd_.y; qf.z = fl * qd_.z;
+  M3 Ro = quat_to_mat(oq.w, oq.x, oq.y, oq.z);
+  V3 up = Ro.c2;
+  const int j1 = limb, j2 = 4 + 2 * limb, j3 = 5 + 2 * limb;
+  float* ob = sObs + envl * 64; float* st = sSt + envl * 93;
+  if (limb == 0) {
+    ob[0] = P->s_pos * opos.x; ob[1] = P->s_pos * opos.y; ob[2] = P->s_pos * opos.z;
+    ob[3] = up.x; ob[4] = up.y; ob[5] = up.z;
+    ob[6] = qf.w; ob[7] = qf.x; ob[8] = qf.y; ob[9] = qf.z;
+    ob[10] = P->s_lin * olin.x; ob[11] = P->s_lin * olin.y; ob[12] = P->s_lin * olin.z;
+    ob[13] = P->s_ang * oang.x; ob[14] = P->s_ang * oang.y; ob[15] = P->s_ang * oang.z;
+    st[0] = P->s_pos * opos.x; st[1] = P->s_pos * opos.y; st[2] = P->s_pos * opos.z;
+    st[3] = P->s_lin * olin.x; st[4] = P->s_lin * olin.y; st[5] = P->s_lin * olin.z;
+    st[6] = oq.w; st[7] = oq.x; st[8] = oq.y; st[9] = oq.z;
+    st[10] = P->s_ang * oang.x; st[11] = P->s_ang * oang.y; st[12] = P->s_ang * oang.z;
+    st[37] = S.goal.w; st[38] = S.goal.x; st[39] = S.goal.y; st[40] = S.goal.z;
+    st[41] = qf.w; st[42] = qf.x; st[43] = qf.y; st[44] = qf.z;
+  }
+  const int jj[3] = {j1, j2, j3};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int j = jj[a];
+    ob[16 + j] = P->s_q * I.q[a]; ob[28 + j] = P->s_qd * I.qd[a]; ob[40 + j] = I.act[a]; ob[52 + j] = S.lact[a];
+    st[13 + j] = P->s_q * I.q[a]; st[25 + j] = P->s_qd * I.qd[a]; st[69 + j] = I.act[a]; st[81 + j] = S.lact[a];
+  }
+  st[45 + 3 * limb] = btip.x; st[46 + 3 * limb] = btip.y; st[47 + 3 * limb] = btip.z;
+  st[57 + 3 * limb] = S.ltip.x; st[58 + 3 * limb] = S.ltip.y; st[59 + 3 * limb] = S.ltip.z;
+  S.ltip = btip;
+  // ---- calculate_metrics
+  float vn = fminf(sqrtf(qd_.x * qd_.x + qd_.y * qd_.y + qd_.z * qd_.z), 1.0f);
+  float rot_dist = 2.0f * asinf(vn);
+  float rot_rew = P->quat_scale / (fabsf(rot_dist) + P->rot_eps);
+  float trans = sqrtf(opos.x * opos.x + opos.y * opos.y) * P->trans_scale;
+  float accp = quad_sum(fabsf(I.acc[0]) * P->acc_scale + fabsf(I.acc[1]) * P->acc_scale + fabsf(I.acc[2]) * P->acc_scale);
+  float rate = quad_sum(fabsf(S.lact[0] - I.act[0]) + fabsf(S.lact[1] - I.act[1]) + fabsf(S.lact[2] - I.act[2])) * P->rate_scale;
+  int cgr = (S.consec > P->max_consec) ? 1 : 0;
+  float bonus = P->bonus * (float)cgr;
+  int succ = (fabsf(rot_dist) <= P->succ_thresh) ? 1 : 0;
+  float dd = fabsf(I.q[2] - I.q[1]);
+  int brk = ((dd < P->d23_pen[0]) || (dd > P->d23_pen[1])) + ((I.q[0] < P->d1_pen[limb][0]) || (I.q[0] > P->d1_pen[limb][1]));
+  int rst = ((dd < P->d23_rst[0]) || (dd > P->d23_rst[1])) + ((I.q[0] < P->d1_rst[limb][0]) || (I.q[0] > P->d1_rst[limb][1]));
+  brk = quad_sum_i(brk); rst = quad_sum_i(rst);
+  float limp = (brk > 0) ? P->limit_pen : 0.f;
+  float total = rot_rew + trans + accp + rate + bonus + limp;
+  S.greset = cgr;
+  int both = (succ && S.succ) ? 1 : 0;
+  int consec = both ? (S.consec + 1) : 0;
+  if (S.succ == 0 && succ == 1) consec = 1;
+  S.consec = consec; S.succ = succ;
+#pragma unroll
+  for (int a = 0; a < 3; a++) S.lact[a] = I.act[a];
+  // ---- is_done
+  int reset = S.reset;
+  if (opos.z > 0.f) reset = 1;
+  M3 Rp; V3 pp;
+  if (MODE == 0) { Rp.c0 = v3(1, 0, 0); Rp.c1 = v3(0, 1, 0); Rp.c2 = v3(0, 0, 1); pp = v3(0, 0, 0); }
+  else { Rp = quat_to_mat(I.fq.w, I.fq.x, I.fq.y, I.fq.z); pp = I.fp; }
+  if (mulT(Rp, pr - pp).z <= P->h_base) reset = 1;
+  V3 cw = pr + mul(Rr, v3(P->corner[limb][0], P->corner[limb][1], P->corner[limb][2]));
+  int nlow = (mulT(Rp, cw - pp).z < P->h_corner) ? 1 : 0;
+  nlow += (mulT(Rp, I.knee2 - pp).z - P->h_knee <= 0.f) ? 1 : 0;
+  nlow += (mulT(Rp, I.knee3 - pp).z - P->h_knee <= 0.f) ? 1 : 0;
+  nlow = quad_sum_i(nlow);
+  if (nlow > 0) reset = 1;
+  if (rst > 0) reset = 1;
+  float fallp = P->fall_pen * (float)reset;
+  total += fallp;
+  if (cgr == 1) reset = 1;
+  if (S.progress >= P->max_episode - 1) reset = 1;
+  S.reset = reset;
+  O.rew = total;
+  O.terms[0] = rot_rew; O.terms[1] = trans; O.terms[2] = accp; O.terms[3] = rate; O.terms[4] = bonus; O.terms[5] = limp; O.terms[6] = fallp; O.terms[7] = (float)cgr;
+}
+
+// shared tail: write staged obs / states, reward, counters, per-block partial sums
+LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
+
+struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms, *partials; float *out_obs, *out_states, *out_rew; int64_t* out_resets; };
+
+LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int N, int env0, int lane, int limb, int env, bool active,
+                          const TaskState& S, const TaskOut& O, int64_t* cnt, int episode, float* sObs, float* sSt) {
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS staging writes landed (single wave per block)
+  __builtin_amdgcn_wave_barrier();
+  const float clip = P->clip_obs;
+  int nenv = min(ENVS_PER_WAVE, N - env0);
+  // obs: nenv*64 floats contiguous
+  for (int i = lane; i < nenv * 16; i += 64) {
+    float4 v = reinterpret_cast<const float4*>(sObs)[i];
+    reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * 64)[i] = v;
+    if (W.out_obs) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
+      reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * 64)[i] = v; }
+  }
+  for (int i = lane; i < nenv * 93; i += 64) {
+    float v = sSt[i];
+    W.states_buf[(size_t)env0 * 93 + i] = v;
+    if (W.out_states) W.out_states[(size_t)env0 * 93 + i] = clampf(v, clip);
+  }
+  if (active && limb == 0) {
+    W.rew_buf[env] = O.rew;
+    if (W.out_rew) W.out_rew[env] = O.rew;
+    if (W.out_resets) W.out_resets[env] = (int64_t)S.reset;
+    cnt[0 * (size_t)N + env] = S.succ; cnt[1 * (size_t)N + env] = S.consec; cnt[2 * (size_t)N + env] = S.greset;
+    cnt[3 * (size_t)N + env] = S.reset; cnt[4 * (size_t)N + env] = S.progress; cnt[5 * (size_t)N + env] = episode;
+#pragma unroll
+    for (int k = 0; k < 8; k++) W.terms[(size_t)k * N + env] = O.terms[k];
+  }
+  // per-block partial sums (fixed order -> deterministic means)
+  float part[9];
+  bool cnts = active && (limb == 0);
+#pragma unroll
+  for (int k = 0; k < 8; k++) part[k] = cnts ? O.terms[k] : 0.f;
+  part[8] = cnts ? (float)S.reset : 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    float v = part[k];
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    part[k] = v;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) W.partials[(size_t)blockIdx.x * NPART + k] = part[k];
+  }
+}
+
+LM_DEV void load_table(const float* __restrict__ table, float* sTab, int lane) {
+  for (int i = lane; i < LM_TABLE_FLOATS; i += 64) sTab[i] = table[i];
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+  const lm_params* params; const float* table; float* state; int64_t* cnt;
+  const float* actions; const float* goal_rand; OutPtrs W; int N, split; uint32_t seed;
+};
+
+template <int MODE>
+LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const float* sTab, float* sObs, float* sSt) {
+  const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
+  const bool active = envr < N; const int env = active ? envr : (N - 1);
+  const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE;
+  const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  float* st = A.state; int64_t* cnt = A.cnt;
+  const int fb = (MODE == 0) ? R_FB0 : R_FB1;
+  // ---- load
+  TaskState S; int episode;
+  S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
+  S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; episode = (int)cnt[5 * (size_t)N + env];
+  FreeBody F; V3 lin, ang; float q[3], qd[3], lqd[3], act[3];
+  F.p = v3(st[(size_t)(fb + 0) * N + env], st[(size_t)(fb + 1) * N + env], st[(size_t)(fb + 2) * N + env]);
+  F.q.w = st[(size_t)(fb + 3) * N + env]; F.q.x = st[(size_t)(fb + 4) * N + env]; F.q.y = st[(size_t)(fb + 5) * N + env]; F.q.z = st[(size_t)(fb + 6) * N + env];
+  lin = v3(st[(size_t)(fb + 7) * N + env], st[(size_t)(fb + 8) * N + env], st[(size_t)(fb + 9) * N + env]);
+  ang = v3(st[(size_t)(fb + 10) * N + env], st[(size_t)(fb + 11) * N + env], st[(size_t)(fb + 12) * N + env]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    q[a] = st[(size_t)(R_Q + jj[a]) * N + env]; qd[a] = st[(size_t)(R_QD + jj[a]) * N + env];
+    S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env]; lqd[a] = st[(size_t)(R_LQD + jj[a]) * N + env];
+    act[a] = clampf(A.actions[(size_t)env * 12 + jj[a]], P->clip_actions);
+  }
+  S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
+  S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
+  // ---- reset_idx (quadruped_pose_control.py:230-299) for flagged envs
+  if (S.reset != 0) {
+    float u3[3];
+    if (A.goal_rand) { u3[0] = A.goal_rand[(size_t)env * 3]; u3[1] = A.goal_rand[(size_t)env * 3 + 1]; u3[2] = A.goal_rand[(size_t)env * 3 + 2]; }
+    else hash_uniform3(A.seed, (uint32_t)env, (uint32_t)episode, u3);
+    S.goal = quat_from_euler(P->goal_lo[0] + (P->goal_hi[0] - P->goal_lo[0]) * u3[0], P->goal_lo[1] + (P->goal_hi[1] - P->goal_lo[1]) * u3[1],
+                             P->goal_lo[2] + (P->goal_hi[2] - P->goal_lo[2]) * u3[2]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { q[a] = P->init_q[jj[a]]; qd[a] = 0.f; S.lact[a] = 0.f; lqd[a] = 0.f; }
+    S.ltip = v3(P->default_tip[3 * limb], P->default_tip[3 * limb + 1], P->default_tip[3 * limb + 2]);
+    const float* ip = (MODE == 0) ? P->init_base_pos : P->init_plate_pos; const float* iq = (MODE == 0) ? P->init_base_quat : P->init_plate_quat;
+    F.p = v3(ip[0], ip[1], ip[2]); F.q.w = iq[0]; F.q.x = iq[1]; F.q.y = iq[2]; F.q.z = iq[3];
+    lin = v3(0, 0, 0); ang = v3(0, 0, 0);
+    S.succ = 0; S.consec = 0; S.greset = 0; S.reset = 0; S.progress = 0; episode += 1;
+  }
+  // world -> body-coordinate twist
+  {
+    M3 R = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
+    F.u = sv(mulT(R, ang), mulT(R, lin));
+  }
+  M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
+  Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
+  // ---- take_action (robot.py:452-454): velocity targets
+  float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
+  // ---- physics
+  for (int s = 0; s < P->substeps; s++) substep<MODE>(P, sTab, tl, limb, F, Rfix, pfix, q, qd, tgt);
+  // ---- read-back (robot.py:276-321)
+  TaskIn I;
+  M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
+  I.fp = F.p; I.fq = F.q; I.lin = mul(Rf, F.u.v); I.ang = mul(Rf, F.u.w);
+  {
+    LimbKin K; float z3[3] = {0.f, 0.f, 0.f};
+    limb_kinematics(tl, q, z3, K);
+    V3 x = K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117]));
+    M3 Rb = (MODE == 0) ? Rf : Rfix; V3 pb = (MODE == 0) ? F.p : pfix;
+    I.tipw = pb + mul(Rb, x); I.knee2 = pb + mul(Rb, K.o2); I.knee3 = pb + mul(Rb, K.o3);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a]; }
+  TaskOut O;
+  task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
+  // ---- store state
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      st[(size_t)(R_Q + jj[a]) * N + env] = q[a]; st[(size_t)(R_QD + jj[a]) * N + env] = qd[a];
+      st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a]; st[(size_t)(R_LQD + jj[a]) * N + env] = qd[a];
+    }
+    st[(size_t)(R_LTIP + 3 * limb) * N + env] = S.ltip.x; st[(size_t)(R_LTIP + 3 * limb + 1) * N + env] = S.ltip.y; st[(size_t)(R_LTIP + 3 * limb + 2) * N + env] = S.ltip.z;
+    if (limb == 0) {
+      st[(size_t)(fb + 0) * N + env] = F.p.x; st[(size_t)(fb + 1) * N + env] = F.p.y; st[(size_t)(fb + 2) * N + env] = F.p.z;
+      st[(size_t)(fb + 3) * N + env] = F.q.w; st[(size_t)(fb + 4) * N + env] = F.q.x; st[(size_t)(fb + 5) * N + env] = F.q.y; st[(size_t)(fb + 6) * N + env] = F.q.z;
+      st[(size_t)(fb + 7) * N + env] = I.lin.x; st[(size_t)(fb + 8) * N + env] = I.lin.y; st[(size_t)(fb + 9) * N + env] = I.lin.z;
+      st[(size_t)(fb + 10) * N + env] = I.ang.x; st[(size_t)(fb + 11) * N + env] = I.ang.y; st[(size_t)(fb + 12) * N + env] = I.ang.z;
+      st[(size_t)(R_GOAL + 0) * N + env] = S.goal.w; st[(size_t)(R_GOAL + 1) * N + env] = S.goal.x; st[(size_t)(R_GOAL + 2) * N + env] = S.goal.y; st[(size_t)(R_GOAL + 3) * N + env] = S.goal.z;
+    }
+  }
+  write_outputs(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt);
+}
+
+__global__ void __launch_bounds__(64) k_step(StepArgs A) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * 64];
+  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
+  load_table(A.table, sTab, threadIdx.x);
+  const int env0 = blockIdx.x * ENVS_PER_WAVE;
+  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+  if (P->mode == LM_MODE_LOCO) step_body<0>(A, P, sTab, sObs, sSt); else step_body<1>(A, P, sTab, sObs, sSt);
+}
+
+// means of the reward terms + success-rate window (quadruped_pose_control.py:560,610,618-633)
+__global__ void __launch_bounds__(64) k_finalize(const float* partials, int nblocks, int N, const lm_params* P, char* stats, float* extras, float* out_extras) {
+  int lane = threadIdx.x;
+  __shared__ float sums[16];
+  if (lane < 9) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * NPART + lane];
+    sums[lane] = s;
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    if (lane < 7) { float m = s / (float)N; extras[lane] = m; if (out_extras) out_extras[lane] = m; }
+    if (lane == 0) {
+      int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 16);
+      int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
+      if (num_rst > (int64_t)P->max_reset_counts) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
+      num_succ += (int64_t)(sums[7] + 0.5f); num_rst += (int64_t)(sums[8] + 0.5f);
+      ns[0] = num_succ; ns[1] = num_rst; *rate = sr;
+      extras[7] = sr; if (out_extras) out_extras[7] = sr;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_reset_all(int64_t* cnt, int N) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < N) cnt[3 * (size_t)N + i] = 1;
+}
+
+// ---- test / tooling kernels ---------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_apply_resets(StepArgs A) {
+  const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; if (envr >= N) return; const int env = envr;
+  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  float* st = A.state; int64_t* cnt = A.cnt;
+  if (cnt[3 * (size_t)N + env] == 0) return;
+  int episode = (int)cnt[5 * (size_t)N + env];
+  float u3[3];
+  if (A.goal_rand) { u3[0] = A.goal_rand[(size_t)env * 3]; u3[1] = A.goal_rand[(size_t)env * 3 + 1]; u3[2] = A.goal_rand[(size_t)env * 3 + 2]; }
+  else hash_uniform3(A.seed, (uint32_t)env, (uint32_t)episode, u3);
+  Q4 g = quat_from_euler(P->goal_lo[0] + (P->goal_hi[0] - P->goal_lo[0]) * u3[0], P->goal_lo[1] + (P->goal_hi[1] - P->goal_lo[1]) * u3[1],
+                         P->goal_lo[2] + (P->goal_hi[2] - P->goal_lo[2]) * u3[2]);
+  for (int a = 0; a < 3; a++) {
+    st[(size_t)(R_Q + jj[a]) * N + env] = P->init_q[jj[a]]; st[(size_t)(R_QD + jj[a]) * N + env] = 0.f;
+    st[(size_t)(R_LACT + jj[a]) * N + env] = 0.f; st[(size_t)(R_LQD + jj[a]) * N + env] = 0.f;
+    st[(size_t)(R_LTIP + 3 * limb + a) * N + env] = P->default_tip[3 * limb + a];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (limb == 0) {
+    for (int k = 0; k < 3; k++) {
+      st[(size_t)(R_FB0 + k) * N + env] = P->init_base_pos[k]; st[(size_t)(R_FB0 + 7 + k) * N + env] = 0.f; st[(size_t)(R_FB0 + 10 + k) * N + env] = 0.f;
+      st[(size_t)(R_FB1 + k) * N + env] = P->init_plate_pos[k]; st[(size_t)(R_FB1 + 7 + k) * N + env] = 0.f; st[(size_t)(R_FB1 + 10 + k) * N + env] = 0.f;
+    }
+    for (int k = 0; k < 4; k++) { st[(size_t)(R_FB0 + 3 + k) * N + env] = P->init_base_quat[k]; st[(size_t)(R_FB1 + 3 + k) * N + env] = P->init_plate_quat[k]; }
+    st[(size_t)(R_GOAL + 0) * N + env] = g.w; st[(size_t)(R_GOAL + 1) * N + env] = g.x; st[(size_t)(R_GOAL + 2) * N + env] = g.y; st[(size_t)(R_GOAL + 3) * N + env] = g.z;
+  }
+}
+__global__ void __launch_bounds__(64) k_apply_resets_cnt(int64_t* cnt, int N) {
+  int i = blockIdx.x * 64 + threadIdx.x; if (i >= N) return;
+  if (cnt[3 * (size_t)N + i] != 0) { cnt[0 * (size_t)N + i] = 0; cnt[1 * (size_t)N + i] = 0; cnt[2 * (size_t)N + i] = 0; cnt[3 * (size_t)N + i] = 0; cnt[4 * (size_t)N + i] = 0; cnt[5 * (size_t)N + i] += 1; }
+}
+
+template <int MODE>
+LM_DEV void load_phys(const float* st, int N, int env, int limb, FreeBody& F, float q[3], float qd[3]) {
+  const int fb = (MODE == 0) ? R_FB0 : R_FB1; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  F.p = v3(st[(size_t)(fb + 0) * N + env], st[(size_t)(fb + 1) * N + env], st[(size_t)(fb + 2) * N + env]);
+  F.q.w = st[(size_t)(fb + 3) * N + env]; F.q.x = st[(size_t)(fb + 4) * N + env]; F.q.y = st[(size_t)(fb + 5) * N + env]; F.q.z = st[(size_t)(fb + 6) * N + env];
+  V3 lin = v3(st[(size_t)(fb + 7) * N + env], st[(size_t)(fb + 8) * N + env], st[(size_t)(fb + 9) * N + env]);
+  V3 ang = v3(st[(size_t)(fb + 10) * N + env], st[(size_t)(fb + 11) * N + env], st[(size_t)(fb + 12) * N + env]);
+  M3 R = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z); F.u = sv(mulT(R, ang), mulT(R, lin));
+  for (int a = 0; a < 3; a++) { q[a] = st[(size_t)(R_Q + jj[a]) * N + env]; qd[a] = st[(size_t)(R_QD + jj[a]) * N + env]; }
+}
+template <int MODE>
+LM_DEV void store_phys(float* st, int N, int env, int limb, const FreeBody& F, const float q[3], const float qd[3]) {
+  const int fb = (MODE == 0) ? R_FB0 : R_FB1; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  for (int a = 0; a < 3; a++) { st[(size_t)(R_Q + jj[a]) * N + env] = q[a]; st[(size_t)(R_QD + jj[a]) * N + env] = qd[a]; }
+  if (limb == 0) {
+    M3 R = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z); V3 lin = mul(R, F.u.v), ang = mul(R, F.u.w);
+    st[(size_t)(fb + 0) * N + env] = F.p.x; st[(size_t)(fb + 1) * N + env] = F.p.y; st[(size_t)(fb + 2) * N + env] = F.p.z;
+    st[(size_t)(fb + 3) * N + env] = F.q.w; st[(size_t)(fb + 4) * N + env] = F.q.x; st[(size_t)(fb + 5) * N + env] = F.q.y; st[(size_t)(fb + 6) * N + env] = F.q.z;
+    st[(size_t)(fb + 7) * N + env] = lin.x; st[(size_t)(fb + 8) * N + env] = lin.y; st[(size_t)(fb + 9) * N + env] = lin.z;
+    st[(size_t)(fb + 10) * N + env] = ang.x; st[(size_t)(fb + 11) * N + env] = ang.y; st[(size_t)(fb + 12) * N + env] = ang.z;
+  }
+}
+
+template <int MODE>
+LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sTab, const float* targets, int n) {
+  const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
+  const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  FreeBody F; float q[3], qd[3], tgt[3];
+  load_phys<MODE>(A.state, N, env, limb, F, q, qd);
+  for (int a = 0; a < 3; a++) tgt[a] = targets[(size_t)env * 12 + jj[a]];
+  M3 Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
+  V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
+  for (int s = 0; s < n; s++) substep<MODE>(P, sTab, tl, limb, F, Rfix, pfix, q, qd, tgt);
+  if (active) store_phys<MODE>(A.state, N, env, limb, F, q, qd);
+}
+__global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* targets, int n) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  load_table(A.table, sTab, threadIdx.x);
+  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  if (P->mode == LM_MODE_LOCO) substeps_body<0>(A, P, sTab, targets, n); else substeps_body<1>(A, P, sTab, targets, n);
+}
+
+__global__ void __launch_bounds__(64) k_fk(StepArgs A, float* tips, float* knees) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  load_table(A.table, sTab, threadIdx.x);
+  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  const int env = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; if (env >= N) return;
+  const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE;
+  FreeBody F; float q[3], qd[3];
+  M3 Rb; V3 pb;
+  if (P->mode == LM_MODE_LOCO) { load_phys<0>(A.state, N, env, limb, F, q, qd); Rb = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z); pb = F.p; }
+  else { load_phys<1>(A.state, N, env, limb, F, q, qd); Rb = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
+         pb = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]); }
+  LimbKin K; float z3[3] = {0, 0, 0}; limb_kinematics(tl, q, z3, K);
+  V3 x = pb + mul(Rb, K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117])));
+  V3 k2 = pb + mul(Rb, K.o2), k3 = pb + mul(Rb, K.o3);
+  float* t = tips + ((size_t)env * 4 + limb) * 3; t[0] = x.x; t[1] = x.y; t[2] = x.z;
+  float* kk = knees + ((size_t)env * 8 + 2 * limb) * 3; kk[0] = k2.x; kk[1] = k2.y; kk[2] = k2.z; kk[3] = k3.x; kk[4] = k3.y; kk[5] = k3.z;
+}
+
+// dense M (18x18) and h (18) of the loco system from the limb-aggregate terms (bring-up / parity tests)
+__global__ void __launch_bounds__(64) k_debug_dyn(StepArgs A, float* Mout, float* hout) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  load_table(A.table, sTab, threadIdx.x);
+  const lm_params* P = A.params;
+  const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
+  const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  FreeBody F; float q[3], qd[3];
+  load_phys<0>(A.state, N, env, limb, F, q, qd);
+  M3 Rb = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
+  SV avp0 = sv(v3(0, 0, 0), P->gravity * row2(Rb));
+  LimbKin K; limb_kinematics(tl, q, qd, K);
+  LimbDyn D; limb_dynamics(tl, K, qd, F.u, avp0, D);
+  float Ac[6][6]; si_to_66(D.Isc, Ac);
+  SI I0 = hub_inertia(sTab); float A0[6][6]; si_to_66(I0, A0);
+  SV b = quad_sum(D.fcs) + I0 * avp0 + fcross(F.u, I0 * F.u);
+  float* M = Mout + (size_t)env * 324; float* h = hout + (size_t)env * 18;
+  float bb[6]; sv_to_arr(b, bb);
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { float v = quad_sum(Ac[i][j]) + A0[i][j]; if (active && limb == 0) M[i * 18 + j] = v; }
+  if (active) {
+    if (limb == 0) for (int i = 0; i < 6; i++) h[i] = bb[i];
+    float f[3][6]; sv_to_arr(D.Fq0, f[0]); sv_to_arr(D.Fq1, f[1]); sv_to_arr(D.Fq2, f[2]);
+    const int hi[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    for (int a = 0; a < 3; a++) {
+      for (int i = 0; i < 6; i++) { M[i * 18 + 6 + jj[a]] = f[a][i]; M[(6 + jj[a]) * 18 + i] = f[a][i]; }
+      for (int c = 0; c < 3; c++) M[(6 + jj[a]) * 18 + 6 + jj[c]] = D.H[hi[a][c]];
+      h[6 + jj[a]] = D.hq[a];
+    }
+  }
+}
+
+template <int MODE>
+LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* rb_all, float* sObs, float* sSt) {
+  const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
+  const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
+  float* st = A.state; int64_t* cnt = A.cnt;
+  const float* rb = rb_all + (size_t)env * 87;
+  TaskIn I; TaskState S; TaskOut O;
+  for (int a = 0; a < 3; a++) { I.q[a] = rb[jj[a]]; I.qd[a] = rb[12 + jj[a]]; I.acc[a] = rb[24 + jj[a]];
+    I.act[a] = clampf(A.actions[(size_t)env * 12 + jj[a]], P->clip_actions); S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env]; }
+  I.fp = v3(rb[36], rb[37], rb[38]); I.fq.w = rb[39]; I.fq.x = rb[40]; I.fq.y = rb[41]; I.fq.z = rb[42];
+  I.lin = v3(rb[43], rb[44], rb[45]); I.ang = v3(rb[46], rb[47], rb[48]);
+  I.tipw = v3(rb[49 + 3 * limb], rb[50 + 3 * limb], rb[51 + 3 * limb]);
+  I.knee2 = v3(rb[61 + 6 * limb], rb[62 + 6 * limb], rb[63 + 6 * limb]); I.knee3 = v3(rb[64 + 6 * limb], rb[65 + 6 * limb], rb[66 + 6 * limb]);
+  S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
+  S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
+  S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
+  S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; int episode = (int)cnt[5 * (size_t)N + env];
+  task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
+  if (active) {
+    for (int a = 0; a < 3; a++) st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a];
+    st[(size_t)(R_LTIP + 3 * limb) * N + env] = S.ltip.x; st[(size_t)(R_LTIP + 3 * limb + 1) * N + env] = S.ltip.y; st[(size_t)(R_LTIP + 3 * limb + 2) * N + env] = S.ltip.z;
+  }
+  write_outputs(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt);
+}
+__global__ void __launch_bounds__(64) k_task_eval(StepArgs A, const float* readback) {
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * 64];
+  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
+  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  if (P->mode == LM_MODE_LOCO) task_only_body<0>(A, P, readback, sObs, sSt); else task_only_body<1>(A, P, readback, sObs, sSt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side (C ABI)
+// ------------------------------------------------------------------------------------------------
+static void derive_params(lm_params* p) {
+  // plate spatial inertia about its origin (plate coordinates) and its inverse (double precision Gauss-Jordan)
+  double m = p->plate_mass, c[3] = {p->plate_com[0], p->plate_com[1], p->plate_com[2]};
+  double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  double IO[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) IO[i][j] = ((i == j) ? (p->plate_inertia[i] + m * cc) : 0.0) - m * c[i] * c[j];
+  p->plate_si[0] = (float)m; p->plate_si[1] = (float)(m * c[0]); p->plate_si[2] = (float)(m * c[1]); p->plate_si[3] = (float)(m * c[2]);
+  p->plate_si[4] = (float)IO[0][0]; p->plate_si[5] = (float)IO[1][1]; p->plate_si[6] = (float)IO[2][2];
+  p->plate_si[7] = (float)IO[0][1]; p->plate_si[8] = (float)IO[0][2]; p->plate_si[9] = (float)IO[1][2];
+  double h[3] = {m * c[0], m * c[1], m * c[2]};
+  double hx[3][3] = {{0, -h[2], h[1]}, {h[2], 0, -h[0]}, {-h[1], h[0], 0}};
+  double A[6][12];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 12; j++) A[i][j] = (j - 6 == i) ? 1.0 : 0.0;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { A[i][j] = IO[i][j]; A[i][3 + j] = hx[i][j]; A[3 + i][j] = -hx[i][j]; A[3 + i][3 + j] = (i == j) ? m : 0.0; }
+  for (int col = 0; col < 6; col++) {
+    int piv = col; for (int r = col + 1; r < 6; r++) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+    if (piv != col) for (int j = 0; j < 12; j++) { double t = A[col][j]; A[col][j] = A[piv][j]; A[piv][j] = t; }
+    double d = A[col][col]; if (d == 0.0) d = 1e-30;
+    for (int j = 0; j < 12; j++) A[col][j] /= d;
+    for (int r = 0; r < 6; r++) if (r != col) { double f = A[r][col]; for (int j = 0; j < 12; j++) A[r][j] -= f * A[col][j]; }
+  }
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) p->plate_phi[6 * i + j] = (float)A[i][6 + j];
+  p->ctrl_dt_inv = (float)(1.0 / ((double)p->dt * (double)p->substeps));
+}
+
+extern "C" {
+
+const char* lm_last_error(void) { return g_err; }
+const char* lm_version(void) { return "lm_engine 0.1 (gfx950)"; }
+
+int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks, int split_env, uint32_t seed) {
+  if (!out || !table || !params) return fail(LM_EINVAL, "lm_create: null argument");
+  if (n_envs <= 0) return fail(LM_EINVAL, "lm_create: n_envs must be positive");
+  if (n_tasks != 1 && n_tasks != 2) return fail(LM_EINVAL, "lm_create: n_tasks must be 1 or 2");
+  if (n_tasks == 2 && (split_env <= 0 || split_env >= n_envs || (split_env % ENVS_PER_WAVE) != 0))
+    return fail(LM_EINVAL, "lm_create: split_env must be a multiple of 16 inside (0, n_envs)");
+  for (int t = 0; t < n_tasks; t++) {
+    const lm_params& p = params[t];
+    if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
+      return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
+  }
+  lm_engine* h = new (std::nothrow) lm_engine();
+  if (!h) return fail(LM_ENOMEM, "lm_create: host allocation failed");
+  memset(h, 0, sizeof(*h));
+  h->N = n_envs; h->n_tasks = n_tasks; h->split = (n_tasks == 2) ? split_env : n_envs; h->seed = seed;
+  h->nblocks = (n_envs + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE;
+  h->h_params[0] = params[0]; h->h_params[1] = params[n_tasks - 1];
+  derive_params(&h->h_params[0]); derive_params(&h->h_params[1]);
+  size_t N = (size_t)n_envs;
+#define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); lm_destroy(h); return LM_EHIP; } \
+    e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMemset: %s", hipGetErrorString(e_)); lm_destroy(h); return LM_EHIP; } } while (0)
+  ALLOC(h->d_params, 2 * sizeof(lm_params));
+  ALLOC(h->d_table, LM_TABLE_FLOATS * sizeof(float));
+  ALLOC(h->d_state, LM_STATE_ROWS * N * sizeof(float));
+  ALLOC(h->d_cnt, LM_CNT_ROWS * N * sizeof(int64_t));
+  ALLOC(h->d_obs, N * 64 * sizeof(float));
+  ALLOC(h->d_states, N * 93 * sizeof(float));
+  ALLOC(h->d_rew, N * sizeof(float));
+  ALLOC(h->d_extras, 16 * sizeof(float));
+  ALLOC(h->d_terms, 8 * N * sizeof(float));
+  ALLOC(h->d_partials, (size_t)h->nblocks * NPART * sizeof(float));
+  ALLOC(h->d_stats, 64);
+#undef ALLOC
+  HIPCHK(hipMemcpy(h->d_params, h->h_params, 2 * sizeof(lm_params), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_table, table, LM_TABLE_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+  // identity quaternions so that an un-reset state is still valid; reset_buf = 1 (rl_task.py:111)
+  {
+    float* tmp = new float[LM_STATE_ROWS * N](); int64_t* ct = new int64_t[LM_CNT_ROWS * N]();
+    for (size_t e = 0; e < N; e++) { tmp[(size_t)(R_FB0 + 3) * N + e] = 1.f; tmp[(size_t)(R_FB1 + 3) * N + e] = 1.f; tmp[(size_t)R_GOAL * N + e] = 1.f; ct[3 * N + e] = 1; }
+    hipError_t e1 = hipMemcpy(h->d_state, tmp, LM_STATE_ROWS * N * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(h->d_cnt, ct, LM_CNT_ROWS * N * sizeof(int64_t), hipMemcpyHostToDevice);
+    delete[] tmp; delete[] ct;
+    if (e1 != hipSuccess || e2 != hipSuccess) { lm_destroy(h); return fail(LM_EHIP, "lm_create: initial upload failed"); }
+  }
+  *out = h;
+  return LM_OK;
+}
+
+int lm_destroy(lm_engine* h) {
+  if (!h) return LM_OK;
+  void* ptrs[] = {h->d_params, h->d_table, h->d_state, h->d_cnt, h->d_obs, h->d_states, h->d_rew, h->d_extras, h->d_terms, h->d_partials, h->d_stats};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete h;
+  return LM_OK;
+}
+
+static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states, float* out_rew, int64_t* out_resets) {
+  StepArgs A;
+  A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
+  A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.partials = h->d_partials;
+  A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
+  A.N = h->N; A.split = h->split; A.seed = h->seed;
+  return A;
+}
+
+int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states, float* out_rew,
+            int64_t* out_resets, float* out_extras, void* stream) {
+  if (!h || !actions) return fail(LM_EINVAL, "lm_step: null handle or actions");
+  hipStream_t s = (hipStream_t)stream;
+  StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets);
+  hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_reset_all(lm_engine* h, void* stream) {
+  if (!h) return fail(LM_EINVAL, "lm_reset_all: null handle");
+  hipLaunchKernelGGL(k_reset_all, dim3((h->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->d_cnt, h->N);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_task_eval(lm_engine* h, const float* readback, const float* actions, float* out_obs, float* out_states, float* out_rew,
+                 int64_t* out_resets, float* out_extras, void* stream) {
+  if (!h || !readback || !actions) return fail(LM_EINVAL, "lm_task_eval: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
+  hipLaunchKernelGGL(k_task_eval, dim3(h->nblocks), dim3(64), 0, s, A, readback);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_apply_resets(lm_engine* h, const float* goal_rand, void* stream) {
+  if (!h) return fail(LM_EINVAL, "lm_apply_resets: null handle");
+  hipStream_t s = (hipStream_t)stream;
+  StepArgs A = make_args(h, nullptr, goal_rand, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_apply_resets, dim3(h->nblocks), dim3(64), 0, s, A);
+  hipLaunchKernelGGL(k_apply_resets_cnt, dim3((h->N + 63) / 64), dim3(64), 0, s, h->d_cnt, h->N);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_substeps(lm_engine* h, const float* targets, int n, void* stream) {
+  if (!h || !targets || n < 0) return fail(LM_EINVAL, "lm_substeps: bad argument");
+  StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_substeps, dim3(h->nblocks), dim3(64), 0, (hipStream_t)stream, A, targets, n);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_forward_kinematics(lm_engine* h, float* tips, float* knees, void* stream) {
+  if (!h || !tips || !knees) return fail(LM_EINVAL, "lm_forward_kinematics: null argument");
+  StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_fk, dim3(h->nblocks), dim3(64), 0, (hipStream_t)stream, A, tips, knees);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_debug_dynamics(lm_engine* h, float* M, float* hvec, void* stream) {
+  if (!h || !M || !hvec) return fail(LM_EINVAL, "lm_debug_dynamics: null argument");
+  if (h->h_params[0].mode != LM_MODE_LOCO || h->n_tasks != 1) return fail(LM_EINVAL, "lm_debug_dynamics: loco engines only");
+  StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_debug_dyn, dim3(h->nblocks), dim3(64), 0, (hipStream_t)stream, A, M, hvec);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+void* lm_ptr(lm_engine* h, int kind) {
+  if (!h) return nullptr;
+  switch (kind) {
+    case LM_PTR_STATE: return h->d_state;
+    case LM_PTR_CNT: return h->d_cnt;
+    case LM_PTR_OBS_BUF: return h->d_obs;
+    case LM_PTR_STATES_BUF: return h->d_states;
+    case LM_PTR_REW_BUF: return h->d_rew;
+    case LM_PTR_EXTRAS: return h->d_extras;
+    case LM_PTR_STATS: return h->d_stats;
+    case LM_PTR_TERMS: return h->d_terms;
+    default: return nullptr;
+  }
+}
+int lm_num_envs(const lm_engine* h) { return h ? h->N : 0; }
+int lm_set_seed(lm_engine* h, uint32_t seed) { if (!h) return fail(LM_EINVAL, "lm_set_seed: null handle"); h->seed = seed; return LM_OK; }
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+"""ctypes binding of the C-ABI engine library (include/lm_engine.h) + zero-copy torch views.
+
+The HIP library is the product path; there is no CPU fallback.  Importing this module never
+touches the GPU; constructing an :class:`Engine` does, and fails loudly when the shared object or
+a HIP device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "liblm_engine.so")
+
+STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS = 90, 6, 64, 93, 12, 8, 486
+PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS = range(8)
+
+# names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
+EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
+           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_set_seed", "lm_last_error", "lm_version"]
+
+# rows of the SoA float state
+ROW = dict(base_pos=0, base_quat=3, base_lin=7, base_ang=10, q=13, qd=25, plate_pos=37, plate_quat=40, plate_lin=44,
+           plate_ang=47, last_actions=50, last_qd=62, last_tip=74, goal=86)
+CNT = dict(successes=0, consecutive_successes=1, goal_reset_buf=2, reset_buf=3, progress_buf=4, episode_count=5)
+
+
+class LmParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_float), ("kd", C.c_float), ("tau_max", C.c_float), ("act_scale", C.c_float), ("mu", C.c_float),
+        ("tip_radius", C.c_float), ("baumgarte", C.c_float), ("max_depen_vel", C.c_float), ("gravity", C.c_float),
+        ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("mode", C.c_int32),
+        ("fixed_base_pos", C.c_float * 3), ("fixed_base_quat", C.c_float * 4),
+        ("plate_mass", C.c_float), ("plate_com", C.c_float * 3), ("plate_inertia", C.c_float * 3),
+        ("plate_half", C.c_float * 3), ("plate_center", C.c_float * 3),
+        ("init_q", C.c_float * 12), ("init_base_pos", C.c_float * 3), ("init_base_quat", C.c_float * 4),
+        ("init_plate_pos", C.c_float * 3), ("init_plate_quat", C.c_float * 4),
+        ("default_tip", C.c_float * 12), ("goal_lo", C.c_float * 3), ("goal_hi", C.c_float * 3),
+        ("s_pos", C.c_float), ("s_lin", C.c_float), ("s_ang", C.c_float), ("s_q", C.c_float), ("s_qd", C.c_float),
+        ("quat_scale", C.c_float), ("rot_eps", C.c_float), ("trans_scale", C.c_float), ("acc_scale", C.c_float),
+        ("rate_scale", C.c_float), ("bonus", C.c_float), ("limit_pen", C.c_float), ("fall_pen", C.c_float),
+        ("succ_thresh", C.c_float),
+        ("max_consec", C.c_int32), ("max_episode", C.c_int32),
+        ("d23_pen", C.c_float * 2), ("d23_rst", C.c_float * 2), ("d1_pen", (C.c_float * 2) * 4), ("d1_rst", (C.c_float * 2) * 4),
+        ("h_base", C.c_float), ("h_corner", C.c_float), ("h_knee", C.c_float), ("corner", (C.c_float * 3) * 4),
+        ("clip_obs", C.c_float), ("clip_actions", C.c_float),
+        ("max_reset_counts", C.c_int32),
+        ("plate_si", C.c_float * 10), ("plate_phi", C.c_float * 36), ("ctrl_dt_inv", C.c_float),
+    ]
+
+
+_DERIVED = {"plate_si", "plate_phi", "ctrl_dt_inv"}
+
+
+def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParams:
+    """EngineParams -> C struct (clipObservations / clipActions: QuadrupedPoseControl.yaml:11-12)."""
+    p = LmParams()
+    for name, _ in LmParams._fields_:
+        if name in _DERIVED:
+            continue
+        if name == "clip_obs":
+            p.clip_obs = float(clip_obs); continue
+        if name == "clip_actions":
+            p.clip_actions = float(clip_actions); continue
+        val = getattr(ep, name)
+        if isinstance(val, (list, tuple, np.ndarray)):
+            arr = np.asarray(val, dtype=np.float64)
+            dst = getattr(p, name)
+            if arr.ndim == 1:
+                for i, x in enumerate(arr):
+                    dst[i] = float(x)
+            else:
+                for i, row in enumerate(arr):
+                    for j, x in enumerate(row):
+                        dst[i][j] = float(x)
+        else:
+            setattr(p, name, val)
+    return p
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/lm_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_CSRC, "lm_engine.hip")
+    deps = [src, os.path.join(_CSRC, "lm_math.h"),
+            os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "lm_engine.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", _SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the engine; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the engine has no CPU fallback)")
+    lib = C.CDLL(_SO)
+    vp, fp, ip = C.c_void_p, C.c_void_p, C.c_int
+    lib.lm_create.argtypes = [C.POINTER(vp), ip, C.c_void_p, C.POINTER(LmParams), ip, ip, C.c_uint32]
+    lib.lm_destroy.argtypes = [vp]
+    lib.lm_step.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, vp]
+    lib.lm_reset_all.argtypes = [vp, vp]
+    lib.lm_task_eval.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, vp]
+    lib.lm_apply_resets.argtypes = [vp, fp, vp]
+    lib.lm_substeps.argtypes = [vp, fp, ip, vp]
+    lib.lm_forward_kinematics.argtypes = [vp, fp, fp, vp]
+    lib.lm_debug_dynamics.argtypes = [vp, fp, fp, vp]
+    lib.lm_ptr.argtypes = [vp, ip]; lib.lm_ptr.restype = vp
+    lib.lm_num_envs.argtypes = [vp]
+    lib.lm_set_seed.argtypes = [vp, C.c_uint32]
+    lib.lm_last_error.restype = C.c_char_p
+    lib.lm_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap handle-owned device memory zero-copy."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+class Engine:
+    """One engine instance = N lock-step environments on one GPU (one process per GPU)."""
+
+    def __init__(self, robot_model, params: Sequence, num_envs: int, split_env: Optional[int] = None, seed: int = 42,
+                 device: str = "cuda:0", clip_obs: float = 5.0, clip_actions: float = 1.0):
+        import torch
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible: the engine runs on MI355X only (no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device(device)
+        self.lib = load_library()
+        self.num_envs = int(num_envs)
+        params = list(params)
+        arr = (LmParams * len(params))(*[make_params(p, clip_obs, clip_actions) for p in params])
+        table = np.ascontiguousarray(robot_model.packed_table(), dtype=np.float32)
+        assert table.shape == (TABLE_FLOATS,)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.lm_create(C.byref(self._h), self.num_envs, table.ctypes.data_as(C.c_void_p), arr, len(params),
+                                    int(split_env or 0), C.c_uint32(seed))
+        self._check(rc)
+        N = self.num_envs
+        self.state = self._wrap(PTR_STATE, (STATE_ROWS, N), "<f4")
+        self.cnt = self._wrap(PTR_CNT, (CNT_ROWS, N), "<i8")
+        self.obs_buf = self._wrap(PTR_OBS_BUF, (N, NUM_OBS), "<f4")
+        self.states_buf = self._wrap(PTR_STATES_BUF, (N, NUM_STATES), "<f4")
+        self.rew_buf = self._wrap(PTR_REW_BUF, (N,), "<f4")
+        self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
+        self.terms = self._wrap(PTR_TERMS, (8, N), "<f4")
+        self.stats_i64 = self._wrap(PTR_STATS, (2,), "<i8")
+
+    # ------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(f"lm_engine error {rc}: {self.lib.lm_last_error().decode()}")
+
+    def _wrap(self, kind: int, shape, typestr: str):
+        ptr = self.lib.lm_ptr(self._h, kind)
+        if not ptr:
+            raise EngineError("lm_ptr returned NULL")
+        return self.torch.as_tensor(_DevArray(ptr, shape, typestr, self), device=self.device)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _f32(self, t, shape):
+        assert t.is_cuda and t.dtype == self.torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape), \
+            (t.device, t.dtype, tuple(t.shape), shape)
+        return t
+
+    # ------------------------------------------------------------------ C-ABI calls
+    def step(self, actions, goal_rand=None, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
+        N = self.num_envs
+        self._f32(actions, (N, NUM_ACTIONS))
+        if goal_rand is not None:
+            self._f32(goal_rand, (N, 3))
+        if out_obs is not None: self._f32(out_obs, (N, NUM_OBS))
+        if out_states is not None: self._f32(out_states, (N, NUM_STATES))
+        if out_rew is not None: self._f32(out_rew, (N,))
+        if out_extras is not None: self._f32(out_extras, (NUM_EXTRAS,))
+        if out_resets is not None:
+            assert out_resets.dtype == self.torch.int64 and tuple(out_resets.shape) == (N,) and out_resets.is_cuda
+        self._check(self.lib.lm_step(self._h, self._p(actions), self._p(goal_rand), self._p(out_obs), self._p(out_states),
+                                     self._p(out_rew), self._p(out_resets), self._p(out_extras), self._stream()))
+
+    def task_eval(self, readback, actions, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
+        N = self.num_envs
+        self._f32(readback, (N, 87)); self._f32(actions, (N, NUM_ACTIONS))
+        self._check(self.lib.lm_task_eval(self._h, self._p(readback), self._p(actions), self._p(out_obs), self._p(out_states),
+                                          self._p(out_rew), self._p(out_resets), self._p(out_extras), self._stream()))
+
+    def reset_all(self):
+        self._check(self.lib.lm_reset_all(self._h, self._stream()))
+
+    def apply_resets(self, goal_rand=None):
+        if goal_rand is not None:
+            self._f32(goal_rand, (self.num_envs, 3))
+        self._check(self.lib.lm_apply_resets(self._h, self._p(goal_rand), self._stream()))
+
+    def substeps(self, targets, n: int = 1):
+        self._f32(targets, (self.num_envs, NUM_ACTIONS))
+        self._check(self.lib.lm_substeps(self._h, self._p(targets), int(n), self._stream()))
+
+    def forward_kinematics(self):
+        N = self.num_envs
+        tips = self.torch.empty((N, 4, 3), dtype=self.torch.float32, device=self.device)
+        knees = self.torch.empty((N, 8, 3), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.lm_forward_kinematics(self._h, self._p(tips), self._p(knees), self._stream()))
+        return tips, knees
+
+    def debug_dynamics(self):
+        N = self.num_envs
+        M = self.torch.zeros((N, 18, 18), dtype=self.torch.float32, device=self.device)
+        h = self.torch.zeros((N, 18), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.lm_debug_dynamics(self._h, self._p(M), self._p(h), self._stream()))
+        return M, h
+
+    def set_seed(self, seed: int):
+        self._check(self.lib.lm_set_seed(self._h, C.c_uint32(seed)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.torch.cuda.synchronize(self.device)
+            self.lib.lm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ convenience (tests / tooling)
+    def set_phys_env_major(self, phys):
+        """phys: (N,50) env-major array in the oracle's LMO_PHYS layout -> rows 0..49 of the SoA state."""
+        t = self.torch.as_tensor(np.ascontiguousarray(phys, dtype=np.float32).T.copy(), device=self.device)
+        self.state[:50].copy_(t)
+
+    def get_phys_env_major(self):
+        return self.state[:50].T.contiguous().cpu().numpy()
+
+    def set_task_env_major(self, task):
+        t = self.torch.as_tensor(np.ascontiguousarray(task, dtype=np.float32).T.copy(), device=self.device)
+        self.state[50:90].copy_(t)
+
+    def get_task_env_major(self):
+        return self.state[50:90].T.contiguous().cpu().numpy()
+
+    def set_cnt_env_major(self, cnt):
+        self.cnt.copy_(self.torch.as_tensor(np.ascontiguousarray(cnt, dtype=np.int64).T.copy(), device=self.device))
+
+    def get_cnt_env_major(self):
+        return self.cnt.T.contiguous().cpu().numpy()

@@ -1,0 +1,93 @@
+"""Bring-up: compare the HIP engine against the float64 oracle stage by stage (run on the GPU box)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from locomanipulationrl_amd.model.robot_model import load_model
+from locomanipulationrl_amd.engine_config import loco_params, mani_params
+from locomanipulationrl_amd.lib import Engine
+from oracle.lmo import Oracle
+
+
+def qmul(a, b):
+    w1, x1, y1, z1 = a.T; w2, x2, y2, z2 = b.T
+    return np.stack([w1*w2-x1*x2-y1*y2-z1*z2, w1*x2+x1*w2+y1*z2-z1*y2, w1*y2-x1*z2+y1*w2+z1*x2, w1*z2+x1*y2-y1*x2+z1*w2], 1)
+
+
+def rand_states(o, ep, N, rng, mode):
+    phys, task, cnt = o.new_state(N)
+    o.reset(phys, task, cnt, seed=1)
+    phys[:, 13:25] += rng.normal(size=(N, 12)) * 0.15
+    phys[:, 25:37] = rng.normal(size=(N, 12)) * 1.0
+    fb = 0 if mode == 0 else 37
+    phys[:, fb + 7:fb + 13] = rng.normal(size=(N, 6)) * 0.3
+    qq = np.concatenate([np.ones((N, 1)), rng.normal(size=(N, 3)) * 0.1], 1)
+    base = np.array([1, 0, 0, 0.]) if mode == 0 else np.array([0, 1, 0, 0.])
+    qq = qmul(qq / np.linalg.norm(qq, axis=1, keepdims=True), np.tile(base, (N, 1)))
+    phys[:, fb + 3:fb + 7] = qq
+    if mode == 0:
+        phys[:, 2] = 0.128 + rng.normal(size=N) * 0.004
+    else:
+        phys[:, 39] = 0.134 + rng.normal(size=N) * 0.003
+        phys[:, 37:39] = rng.normal(size=(N, 2)) * 0.01
+    return phys, task, cnt
+
+
+def main():
+    rm = load_model("quadruped_robot_v2")
+    rng = np.random.default_rng(0)
+    for mode, ep in ((0, loco_params()), (1, mani_params())):
+        N = 48
+        o = Oracle(rm, ep)
+        eng = Engine(rm, [ep], N)
+        phys, task, cnt = rand_states(o, ep, N, rng, mode)
+        eng.set_phys_env_major(phys)
+        tips, knees = eng.forward_kinematics()
+        ot, ok = o.fk(phys)
+        print(f"[mode {mode}] fk tip diff {np.abs(tips.cpu().numpy()-ot).max():.2e} knee diff {np.abs(knees.cpu().numpy()-ok).max():.2e}", flush=True)
+        if mode == 0:
+            M, h = eng.debug_dynamics(); M = M.cpu().numpy(); h = h.cpu().numpy()
+            dM = dh = 0; sM = sh = 0
+            for e in range(N):
+                Mo, ho = o.dyn_terms(phys[e])
+                dM = max(dM, np.abs(M[e] - Mo).max()); dh = max(dh, np.abs(h[e] - ho).max()); sM = max(sM, np.abs(Mo).max()); sh = max(sh, np.abs(ho).max())
+            print(f"[mode {mode}] dyn M diff {dM:.3e} (scale {sM:.2e})  h diff {dh:.3e} (scale {sh:.2e})", flush=True)
+        tg = rng.uniform(-3, 3, size=(N, 12))
+        for nsub in (1, 4):
+            p2 = phys.copy(); eng.set_phys_env_major(phys)
+            for s in range(nsub): o.substep(p2, tg)
+            eng.substeps(torch.as_tensor(tg, dtype=torch.float32, device="cuda"), nsub)
+            g = eng.get_phys_env_major()
+            d = np.abs(g - p2)
+            fb = 0 if mode == 0 else 37
+            print(f"[mode {mode}] {nsub} substep(s): max diff pose {d[:, fb:fb+7].max():.2e} q {d[:,13:25].max():.2e} qd {d[:,25:37].max():.2e} "
+                  f"fbvel {d[:, fb+7:fb+13].max():.2e}", flush=True)
+            worst = np.unravel_index(d[:, 25:37].argmax(), (N, 12)); print("   worst qd at", worst, g[worst[0], 25 + worst[1]], p2[worst[0], 25 + worst[1]])
+        # full step parity from reset
+        phys, task, cnt = o.new_state(N)
+        eng2 = Engine(rm, [ep], N, seed=42)
+        act = rng.uniform(-1, 1, size=(N, 12)).astype(np.float32)
+        for t in range(3):
+            obs, states, rew, terms = o.step(phys, task, cnt, act.astype(np.float64), seed=42)
+            oo = torch.empty(N, 64, device="cuda"); ss = torch.empty(N, 93, device="cuda"); rr = torch.empty(N, device="cuda")
+            rs = torch.empty(N, dtype=torch.int64, device="cuda"); ex = torch.empty(8, device="cuda")
+            eng2.step(torch.as_tensor(act, device="cuda"), None, oo, ss, rr, rs, ex)
+            torch.cuda.synchronize()
+            print(f"[mode {mode}] step {t}: obs diff {np.abs(oo.cpu().numpy()-np.clip(obs,-5,5)).max():.2e} states {np.abs(ss.cpu().numpy()-np.clip(states,-5,5)).max():.2e} "
+                  f"rew {np.abs(rr.cpu().numpy()-rew).max():.2e} resets eq {np.array_equal(rs.cpu().numpy(), cnt[:,3])} extras {ex.cpu().numpy().round(4)} ref {terms[:,:7].mean(0).round(4)}", flush=True)
+        # timing
+        Nb = 4096
+        engb = Engine(rm, [ep], Nb)
+        a = torch.rand(Nb, 12, device="cuda") * 2 - 1
+        oo = torch.empty(Nb, 64, device="cuda"); ss = torch.empty(Nb, 93, device="cuda"); rr = torch.empty(Nb, device="cuda")
+        rs = torch.empty(Nb, dtype=torch.int64, device="cuda"); ex = torch.empty(8, device="cuda")
+        for _ in range(20): engb.step(a, None, oo, ss, rr, rs, ex)
+        torch.cuda.synchronize(); t0 = time.time()
+        K = 200
+        for _ in range(K): engb.step(a, None, oo, ss, rr, rs, ex)
+        torch.cuda.synchronize(); dtm = (time.time() - t0) / K
+        print(f"[mode {mode}] N={Nb}: {dtm*1e6:.1f} us/step -> {Nb/dtm/1e6:.2f} M env-steps/s; resets now {int(rs.sum())} rew mean {float(rr.mean()):.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
