@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of VecEnv step() on the horizontal-locomotion task, 4096 envs per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one lm_step over the rank's 4096 environments = reset scatter + action clamp/scale + 4 physics
+sub-steps + observations / reward / termination (reference: VecEnvRLGames.step, vec_env_rlgames.py:56-79).
+Actions are fresh U(-1,1) draws per step (BASELINE config 2, like scripts/random_policy.py:57) taken from a pool
+resident in HBM before the timed region.  N > 1 = weak scaling: every rank owns 4096 envs; every 48 steps
+(the PPO rollout length, skrl_ppo_locomotion.py:86) the ranks all-gather a (2, 48, N_local) fp32 payload --
+the size of the rollout's returns + advantages -- over RCCL, inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+ROLLOUT = 48
+BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (460 read + 1028 written)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
+FLOP_PER_ENV_STEP = 0.52e6         # counted from the kernel ISA: VALU flops per env-step
+
+
+def cpu_baseline(steps: int = 150, envs: int = 4096):
+    """The CPU oracle (float32 build, OpenMP over envs) timed on this host on a bounded sample of the same workload."""
+    import numpy as np
+    from locomanipulationrl_amd.engine_config import loco_params
+    from locomanipulationrl_amd.model.robot_model import load_model
+    from oracle.lmo import Oracle
+    cores = os.cpu_count() or 1
+    cores = min(cores, 64)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    o = Oracle(load_model("quadruped_robot_v2"), loco_params(), "f32")
+    phys, task, cnt = o.new_state(envs)
+    rng = np.random.default_rng(42)
+    acts = rng.uniform(-1, 1, size=(steps + 2, envs, 12)).astype(np.float32)
+    o.step(phys, task, cnt, acts[0], seed=42); o.step(phys, task, cnt, acts[1], seed=42)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        o.step(phys, task, cnt, acts[2 + t], seed=42)
+    dt = time.perf_counter() - t0
+    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{envs} envs x {steps} steps of the same task on the CPU oracle (fp32 build, OpenMP over envs, {dt:.1f} s); "
+                      "PhysX-CPU itself is unavailable (closed source, not installed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from locomanipulationrl_amd import distributed as D
+    from locomanipulationrl_amd.engine_config import loco_params
+    from locomanipulationrl_amd.lib import Engine
+    from locomanipulationrl_amd.model.robot_model import load_model
+
+    rank, local_rank, world = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    N = ENVS_PER_GPU
+    eng = Engine(load_model("quadruped_robot_v2"), [loco_params()], N, seed=42 + rank, device=str(dev))
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    pool = [torch.rand(N, 12, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
+    out_obs = [torch.empty(N, 64, device=dev) for _ in range(2)]
+    out_states = [torch.empty(N, 93, device=dev) for _ in range(2)]
+    out_extras = torch.empty(8, device=dev)
+    roll_rew = torch.zeros(ROLLOUT, N, device=dev)           # the kernel writes rewards / dones straight into the rollout slots
+    roll_done = torch.zeros(ROLLOUT, N, dtype=torch.int64, device=dev)
+    payload = torch.zeros(2, ROLLOUT, N, device=dev)
+    gathered = torch.empty(2 * world, ROLLOUT, N, device=dev) if world > 1 else None
+
+    def one_step(t):
+        k = t % ROLLOUT
+        eng.step(pool[t % 64], None, out_obs[t & 1], out_states[t & 1], roll_rew[k], roll_done[k], out_extras)
+        if world > 1 and k == ROLLOUT - 1:
+            payload[0].copy_(roll_rew); payload[1].copy_(roll_done)
+            dist.all_gather_into_tensor(gathered, payload)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for t in range(args.warmup):
+        one_step(t)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        one_step(args.warmup + t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out_obs[0]).all() and torch.isfinite(roll_rew).all()
+
+    result = None
+    if rank == 0:
+        # dominant-kernel time: HIP events around each launch on the launch stream (outside the timed region)
+        n_ev = 200
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for i, (a, b) in enumerate(evs):
+            a.record(); eng.step(pool[i % 64], None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras); b.record()
+        torch.cuda.synchronize(dev)
+        k_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        k_avg_ms = sum(k_ms) / len(k_ms)
+        achieved = BYTES_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e9
+        value = world * N * args.steps / elapsed
+        result = {
+            "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
+                                   "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
+                       "envs_per_gpu": N, "global_envs": world * N, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_step(+k_finalize)", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
+                         "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
+            "valu": {"achieved": FLOP_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": FLOP_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64},
+        }
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

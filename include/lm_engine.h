@@ -97,6 +97,14 @@ int lm_destroy(lm_engine* h);
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states,
             float* out_rew, int64_t* out_resets, float* out_extras, void* stream);
 
+/* Staged form of lm_step for callers that drive the reference's three phases themselves
+ * (scripts/random_policy.py:57-61): lm_apply_resets = the reset part of pre_physics_step,
+ * lm_substeps(...,1) = one world.step, lm_post_physics = post_physics_step (state read-back,
+ * observations, reward, termination; rl_task.py:240-260).  Running apply_resets, controlFrequencyInv
+ * sub-steps and post_physics gives the same state as one lm_step. */
+int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* out_states, float* out_rew,
+                    int64_t* out_resets, float* out_extras, void* stream);
+
 /* RLTask.reset(): flag every env for reset (rl_task.py:227-230). */
 int lm_reset_all(lm_engine* h, void* stream);
 

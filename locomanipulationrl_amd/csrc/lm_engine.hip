@@ -252,7 +252,8 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     V3 xw = pb + mul(Rb, D.x);
     V3 y0 = mulT(Rf, xw - F.p);
     V3 y = y0 - v3(P->plate_center[0], P->plate_center[1], P->plate_center[2]);
-    float sg = (y.z >= 0.f) ? 1.f : -1.f;
+    // contact face = the slab face on the robot's side of the plate (robust to deep initial overlap)
+    float sg = (mulT(Rf, pb - F.p).z - P->plate_center[2] >= 0.f) ? 1.f : -1.f;
     phi = sg * y.z - P->plate_half[2] - P->tip_radius;
     if (fabsf(y.x) > P->plate_half[0] || fabsf(y.y) > P->plate_half[1]) phi = 1.0e3f;
     // contact axes in plate coords: n=(0,0,sg) t1=(1,0,0) t2=(0,sg,0); in hub coords: Rb^T Rf axis
@@ -550,6 +551,8 @@ LM_DEV void load_table(const float* __restrict__ table, float* sTab, int lane) {
 struct StepArgs {
   const lm_params* params; const float* table; float* state; int64_t* cnt;
   const float* actions; const float* goal_rand; OutPtrs W; int N, split; uint32_t seed;
+  int skip_reset;   // 1: leave reset_buf untouched (staged API: resets were applied by lm_apply_resets)
+  int nsub;         // < 0: params.substeps, otherwise that many sub-steps (0 = read-back + task layer only)
 };
 
 template <int MODE>
@@ -579,7 +582,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
   S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
   // ---- reset_idx (quadruped_pose_control.py:230-299) for flagged envs
-  if (S.reset != 0) {
+  if (S.reset != 0 && !A.skip_reset) {
     float u3[3];
     if (A.goal_rand) { u3[0] = A.goal_rand[(size_t)env * 3]; u3[1] = A.goal_rand[(size_t)env * 3 + 1]; u3[2] = A.goal_rand[(size_t)env * 3 + 2]; }
     else hash_uniform3(A.seed, (uint32_t)env, (uint32_t)episode, u3);
@@ -603,7 +606,8 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   // ---- take_action (robot.py:452-454): velocity targets
   float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
   // ---- physics
-  for (int s = 0; s < P->substeps; s++) substep<MODE>(P, sTab, tl, limb, F, Rfix, pfix, q, qd, tgt);
+  const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
+  for (int s = 0; s < nsub; s++) substep<MODE>(P, sTab, tl, limb, F, Rfix, pfix, q, qd, tgt);
   // ---- read-back (robot.py:276-321)
   TaskIn I;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
@@ -648,24 +652,31 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   if (P->mode == LM_MODE_LOCO) step_body<0>(A, P, sTab, sObs, sSt); else step_body<1>(A, P, sTab, sObs, sSt);
 }
 
-// means of the reward terms + success-rate window (quadruped_pose_control.py:560,610,618-633)
-__global__ void __launch_bounds__(64) k_finalize(const float* partials, int nblocks, int N, const lm_params* P, char* stats, float* extras, float* out_extras) {
-  int lane = threadIdx.x;
-  __shared__ float sums[16];
-  if (lane < 9) {
-    float s = 0.f;
-    for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * NPART + lane];
-    sums[lane] = s;
-    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    if (lane < 7) { float m = s / (float)N; extras[lane] = m; if (out_extras) out_extras[lane] = m; }
-    if (lane == 0) {
-      int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 16);
-      int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
-      if (num_rst > (int64_t)P->max_reset_counts) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
-      num_succ += (int64_t)(sums[7] + 0.5f); num_rst += (int64_t)(sums[8] + 0.5f);
-      ns[0] = num_succ; ns[1] = num_rst; *rate = sr;
-      extras[7] = sr; if (out_extras) out_extras[7] = sr;
-    }
+// means of the reward terms + success-rate window (quadruped_pose_control.py:560,610,618-633).
+// 256 threads: thread (c, k) sums every 16th block's partial k in a fixed order, then a fixed-order LDS tree
+// -> deterministic, and no serial 256-long dependent-load chain.
+__global__ void __launch_bounds__(256) k_finalize(const float* partials, int nblocks, int N, const lm_params* P, char* stats, float* extras, float* out_extras) {
+  __shared__ float red[16][16];
+  const int k = threadIdx.x & 15, c = threadIdx.x >> 4;
+  float s = 0.f;
+  if (k < 9) for (int b = c; b < nblocks; b += 16) s += partials[(size_t)b * NPART + k];
+  red[c][k] = s;
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += red[i][threadIdx.x];
+    red[0][threadIdx.x] = t;
+    if (threadIdx.x < 7) { float m = t / (float)N; extras[threadIdx.x] = m; if (out_extras) out_extras[threadIdx.x] = m; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 16);
+    int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
+    if (num_rst > (int64_t)P->max_reset_counts) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
+    num_succ += (int64_t)(red[0][7] + 0.5f); num_rst += (int64_t)(red[0][8] + 0.5f);
+    ns[0] = num_succ; ns[1] = num_rst; *rate = sr;
+    extras[7] = sr; if (out_extras) out_extras[7] = sr;
   }
 }
 
@@ -928,7 +939,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
   A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.partials = h->d_partials;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
-  A.N = h->N; A.split = h->split; A.seed = h->seed;
+  A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1;
   return A;
 }
 
@@ -938,7 +949,19 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets);
   hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  HIPCHK(hipGetLastError());
+  return LM_OK;
+}
+
+int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* out_states, float* out_rew,
+                    int64_t* out_resets, float* out_extras, void* stream) {
+  if (!h || !actions) return fail(LM_EINVAL, "lm_post_physics: null handle or actions");
+  hipStream_t s = (hipStream_t)stream;
+  StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
+  A.skip_reset = 1; A.nsub = 0;
+  hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -956,7 +979,7 @@ int lm_task_eval(lm_engine* h, const float* readback, const float* actions, floa
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
   hipLaunchKernelGGL(k_task_eval, dim3(h->nblocks), dim3(64), 0, s, A, readback);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }

@@ -20,7 +20,7 @@ STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS
 PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS = range(8)
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
-EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
+EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
            "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_set_seed", "lm_last_error", "lm_version"]
 
 # rows of the SoA float state
@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
     lib.lm_create.argtypes = [C.POINTER(vp), ip, C.c_void_p, C.POINTER(LmParams), ip, ip, C.c_uint32]
     lib.lm_destroy.argtypes = [vp]
     lib.lm_step.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, vp]
+    lib.lm_post_physics.argtypes = [vp, fp, fp, fp, fp, fp, fp, vp]
     lib.lm_reset_all.argtypes = [vp, vp]
     lib.lm_task_eval.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, vp]
     lib.lm_apply_resets.argtypes = [vp, fp, vp]
@@ -208,6 +209,11 @@ class Engine:
             assert out_resets.dtype == self.torch.int64 and tuple(out_resets.shape) == (N,) and out_resets.is_cuda
         self._check(self.lib.lm_step(self._h, self._p(actions), self._p(goal_rand), self._p(out_obs), self._p(out_states),
                                      self._p(out_rew), self._p(out_resets), self._p(out_extras), self._stream()))
+
+    def post_physics(self, actions, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
+        self._f32(actions, (self.num_envs, NUM_ACTIONS))
+        self._check(self.lib.lm_post_physics(self._h, self._p(actions), self._p(out_obs), self._p(out_states), self._p(out_rew),
+                                             self._p(out_resets), self._p(out_extras), self._stream()))
 
     def task_eval(self, readback, actions, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
         N = self.num_envs

@@ -1,0 +1,242 @@
+"""Concrete tasks of the hot path (names, constructor signature and class constants of the reference):
+
+  QuadrupedPoseControl            tasks/quadruped_pose_control_tasks/quadruped_pose_control.py
+  QuadrupedPoseControlVertical    tasks/quadruped_pose_control_tasks/quadruped_pose_control_vertical.py
+  QuadrupedManipulatePlate        tasks/quadruped_manipulate_plate/quadruped_manipulate_plate.py
+  QuadrupedManipulatePlateVertical tasks/quadruped_manipulate_plate/quadruped_manipulate_plate_vertical.py
+  JointLocomanipulation(/Vertical) tasks/joint_train_locomanipulation/joint_locomanipulation(_vertical).py
+
+The class attributes are the reference's (quadruped_pose_control.py:27-87); they are compiled into the
+engine's parameter block, so editing them on a subclass changes the kernels' behaviour exactly as it changes
+the reference's torch code.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+from ..engine_config import MODE_LOCO, MODE_MANI, EngineParams
+from ..robot.quadruped_robot import (QuadrupedRobotOVFixedBaseOmni, QuadrupedRobotOVOmni, QuadrupedRobotVerticalOVFixedOmni,
+                                     QuadrupedRobotVerticalOVOmni)
+from .base.rl_task import RLTask
+
+_TASK_INIT_Q = [-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4
+_H_CORNERS = [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04], [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]]
+_V_CORNERS = [[0.0, -0.115, -0.1853], [0.0, 0.115, -0.1853], [-0.115, 0.0, -0.1853], [0.115, 0.0, -0.1853]]
+
+
+class _QuadrupedTask(RLTask):
+    # observation scales (quadruped_pose_control.py:27-34)
+    ground_position_scale = 5
+    ground_quaternion_scale = 1
+    ground_linear_vel_scale = 2
+    ground_angular_vel_scale = 0.25
+    base_tip_position_scale = 1
+    joint_position_scale = 0.3
+    joint_velocity_scale = 0.3
+    clip_reward = False
+    # goal ranges (:38-43)
+    min_roll, max_roll, min_pitch, max_pitch, min_yaw, max_yaw = -0.4, 0.4, -0.4, 0.4, -1.57, 1.57
+    # reward scales (:54-61)
+    quaternion_scale = 0.5
+    rot_eps = 0.1
+    translation_scale = -2.5
+    joint_acc_scale = -0.0005
+    action_rate_scale = -0.02
+    # reset thresholds (:64-67)
+    baseline_knee_height = 0.04
+    fall_penalty = 0.0
+    baseline_height = 0.05
+    baseline_corner_height = 0.01
+    # goal thresholds (:70-72); the bonus actually paid is the literal 600 (:457)
+    success_thresh = 0.15
+    success_bonus = 3
+    consecutive_success_bonus = 600.0
+    max_consecutive_successes = 15
+    # joint limits (:79-87)
+    joint_limit_penalty = -5
+    min_joint_23_diff, max_joint_23_diff = 0.43, 2.53
+    reset_min_joint_23_diff, reset_max_joint_23_diff = 0.384, 2.61
+    min_joint_1_pos, max_joint_1_pos = -2.35, 0.78
+    reset_min_joint_1_pos, reset_max_joint_1_pos = -2.44, 0.87
+    mirrored_dof1_limits = True          # a2/a3 use the mirrored window (:482-501); vertical tasks use one symmetric window
+    corner_points = _H_CORNERS
+
+    def __init__(self, sim_config, name, env=None, offset=None) -> None:
+        super().__init__(name, env, offset, sim_config=sim_config)
+        if self.clip_reward:
+            raise NotImplementedError("clip_reward=True is never set on the reference's hot path")
+
+    # ---- helpers ------------------------------------------------------------------
+    def _common(self, robot, **kw) -> EngineParams:
+        sim = self._task_cfg["sim"]; eng = sim.get("engine", {})
+        mat = sim.get("default_physics_material", {}); gnd = sim.get("ground_material", None)
+        mu_body = float(mat.get("dynamic_friction", 1.0))
+        if gnd is not None and kw.get("mode", MODE_LOCO) == MODE_LOCO:
+            comb = eng.get("friction_combine", "average")       # PhysX default combine mode
+            mu_g = float(gnd.get("dynamic_friction", 0.0))
+            mu = {"average": 0.5 * (mu_body + mu_g), "min": min(mu_body, mu_g), "max": max(mu_body, mu_g), "multiply": mu_body * mu_g}[comb]
+        else:
+            mu = mu_body
+        rd = robot.robot_description
+        if rd.control_mode != "velocity":
+            raise NotImplementedError("only the velocity drive (the mode every task on this path uses) is implemented")
+        lo1, hi1 = self.min_joint_1_pos, self.max_joint_1_pos
+        rlo1, rhi1 = self.reset_min_joint_1_pos, self.reset_max_joint_1_pos
+        if self.mirrored_dof1_limits:
+            d1_pen = [[lo1, hi1], [-hi1, -lo1], [-hi1, -lo1], [lo1, hi1]]
+            d1_rst = [[rlo1, rhi1], [-rhi1, -rlo1], [-rhi1, -rlo1], [rlo1, rhi1]]
+        else:
+            d1_pen = [[lo1, hi1]] * 4; d1_rst = [[rlo1, rhi1]] * 4
+        g = sim.get("gravity", [0, 0, -9.81])
+        base = dict(
+            dt=float(sim["dt"]), substeps=int(self.control_frequency_inv), pgs_iters=int(eng.get("pgs_iters", 8)), gravity=float(-g[2]),
+            kd=float(rd.joint_kds[0]), tau_max=float(rd.torque_limits[0]), act_scale=float(rd.velocity_limits[0]), mu=mu,
+            tip_radius=float(eng.get("tip_radius", 0.002)), baumgarte=float(eng.get("baumgarte", 0.2)),
+            max_depen_vel=float(eng.get("max_depenetration_velocity", 1.0)),
+            init_q=list(rd.init_joint_pos[:12]),
+            goal_lo=[self.min_roll, self.min_pitch, self.min_yaw], goal_hi=[self.max_roll, self.max_pitch, self.max_yaw],
+            s_pos=float(self.ground_position_scale), s_lin=float(self.ground_linear_vel_scale), s_ang=float(self.ground_angular_vel_scale),
+            s_q=float(self.joint_position_scale), s_qd=float(self.joint_velocity_scale),
+            quat_scale=float(self.quaternion_scale), rot_eps=float(self.rot_eps), trans_scale=float(self.translation_scale),
+            acc_scale=float(self.joint_acc_scale), rate_scale=float(self.action_rate_scale), bonus=float(self.consecutive_success_bonus),
+            limit_pen=float(self.joint_limit_penalty), fall_pen=float(self.fall_penalty), succ_thresh=float(self.success_thresh),
+            max_consec=int(self.max_consecutive_successes), max_episode=int(self._max_episode_length),
+            d23_pen=[self.min_joint_23_diff, self.max_joint_23_diff], d23_rst=[self.reset_min_joint_23_diff, self.reset_max_joint_23_diff],
+            d1_pen=d1_pen, d1_rst=d1_rst, h_base=float(self.baseline_height), h_corner=float(self.baseline_corner_height),
+            h_knee=float(self.baseline_knee_height), corner=[list(c) for c in self.corner_points],
+        )
+        base.update(kw)
+        return EngineParams(**base)
+
+    def _loco_params(self, robot) -> EngineParams:
+        rd = robot.robot_description
+        return self._common(robot, mode=MODE_LOCO, init_base_pos=list(rd.default_position), init_base_quat=list(rd.default_quaternion))
+
+    def _mani_params(self, robot, plate_pos) -> EngineParams:
+        rd = robot.robot_description
+        return self._common(robot, mode=MODE_MANI, fixed_base_pos=list(rd.default_position), fixed_base_quat=list(rd.default_quaternion),
+                            init_plate_pos=list(plate_pos), init_plate_quat=list(rd.default_quaternion))
+
+
+class QuadrupedPoseControl(_QuadrupedTask):
+    """Horizontal locomotion (configs 1, 2)."""
+
+    def __init__(self, sim_config, name="QuadrupedPoseControl", env=None, offset=None) -> None:
+        self.robot_locomotion = QuadrupedRobotOVOmni()
+        self.robot_locomotion.robot_description.init_joint_pos = list(_TASK_INIT_Q)          # quadruped_pose_control.py:94-102
+        self.robot_locomotion.robot_description.default_position = [0.0, 0.0, 0.14]          # :103
+        super().__init__(sim_config, name, env, offset)
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._loco_params(self.robot_locomotion)]
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory); self.robot_locomotion.bind(e); return e
+
+
+class QuadrupedPoseControlVertical(QuadrupedPoseControl):
+    """Vertical configuration (config 5): quadfinger model, symmetric dof1 limits, different corner points
+    (quadruped_pose_control_vertical.py:84-87,123-126).  The committed reference zeroes the actions
+    (:204, a debug leftover); that is deliberately not reproduced."""
+    model_asset = "quadfinger"
+    success_bonus = 5
+    min_joint_1_pos, max_joint_1_pos = -2.09, 2.09
+    reset_min_joint_1_pos, reset_max_joint_1_pos = -2.26, 2.26
+    mirrored_dof1_limits = False
+    corner_points = _V_CORNERS
+
+    def __init__(self, sim_config, name="QuadrupedPoseControlVertical", env=None, offset=None) -> None:
+        self.robot_locomotion = QuadrupedRobotVerticalOVOmni()
+        _QuadrupedTask.__init__(self, sim_config, name, env, offset)
+
+
+class QuadrupedManipulatePlate(_QuadrupedTask):
+    """Horizontal manipulation (config 3): inverted fixed-base robot + 2.4 kg plate."""
+    default_obj_position = [0.0, 0.0, 0.14]           # quadruped_manipulate_plate.py:150
+
+    def __init__(self, sim_config, name="QuadrupedManipulatePlate", env=None, offset=None) -> None:
+        self.robot_manipulation = QuadrupedRobotOVFixedBaseOmni()
+        rd = self.robot_manipulation.robot_description
+        rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = [0.0, 0.0, 0.0]    # :92-93
+        rd.init_joint_pos = list(_TASK_INIT_Q)                                                  # :94-102
+        super().__init__(sim_config, name, env, offset)
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._mani_params(self.robot_manipulation, self.default_obj_position)]
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory); self.robot_manipulation.bind(e); return e
+
+    # plate read-back (objects/base/rigid_object.py:52-58)
+    @property
+    def plate_pos_ground(self): return self.engine.state[37:40].T
+    @property
+    def plate_quat_ground(self): return self.engine.state[40:44].T
+
+
+class QuadrupedManipulatePlateVertical(QuadrupedManipulatePlate):
+    model_asset = "quadfinger"
+    success_bonus = 5
+    min_joint_1_pos, max_joint_1_pos = -2.09, 2.09
+    reset_min_joint_1_pos, reset_max_joint_1_pos = -2.26, 2.26
+    mirrored_dof1_limits = False
+    corner_points = _V_CORNERS
+    default_obj_position = [0.0, 0.0, 0.35]           # quadruped_manipulate_plate_vertical.py:141
+
+    def __init__(self, sim_config, name="QuadrupedManipulatePlateVertical", env=None, offset=None) -> None:
+        self.robot_manipulation = QuadrupedRobotVerticalOVFixedOmni()
+        rd = self.robot_manipulation.robot_description
+        rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = [0.0, 0.0, 0.0]
+        _QuadrupedTask.__init__(self, sim_config, name, env, offset)
+
+
+class JointLocomanipulation(_QuadrupedTask):
+    """Co-training (config 4): envs [0, N/2) locomotion, [N/2, N) manipulation, one observation tensor,
+    states_buf aliases obs_buf (joint_locomanipulation.py:25-34,139,198,544-548).  The committed reference pins
+    the goal to a single orientation and exits after recording two trajectories (:61-66,861-874); the ranges of
+    the single tasks are used instead."""
+    _num_states = 64
+    default_obj_position = [0.0, 0.0, 0.68]
+    mani_base_position = [0.0, 0.0, 0.5]
+
+    def __init__(self, sim_config, name="JointLocomanipulation", env=None, offset=None) -> None:
+        self.robot_locomotion = QuadrupedRobotOVOmni()
+        self.robot_manipulation = QuadrupedRobotOVFixedBaseOmni()
+        rd = self.robot_manipulation.robot_description
+        rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = list(self.mani_base_position)
+        super().__init__(sim_config, name, env, offset)
+        self._single_task_num_envs = self._num_envs // 2
+        assert self._single_task_num_envs * 2 == self._num_envs, "Number of envs must be a multiplier of 2. "
+        assert self._single_task_num_envs % 16 == 0, "each half must be a multiple of 16 envs (one wavefront = 16 envs)"
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._loco_params(self.robot_locomotion), self._mani_params(self.robot_manipulation, self.default_obj_position)]
+
+    def split_env(self) -> Optional[int]:
+        return self._num_envs // 2
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory)
+        h = self._num_envs // 2
+        self.robot_locomotion.bind(e, slice(0, h)); self.robot_manipulation.bind(e, slice(h, None))
+        return e
+
+
+class JointLocomanipulationVertical(JointLocomanipulation):
+    model_asset = "quadfinger"
+    success_bonus = 5
+    min_joint_1_pos, max_joint_1_pos = -2.09, 2.09
+    reset_min_joint_1_pos, reset_max_joint_1_pos = -2.26, 2.26
+    mirrored_dof1_limits = False
+    corner_points = _V_CORNERS
+    default_obj_position = [0.0, 0.0, 0.95]       # joint_locomanipulation_vertical.py:166
+    mani_base_position = [0.0, 0.0, 0.6]          # :108
+
+    def __init__(self, sim_config, name="JointLocomanipulationVertical", env=None, offset=None) -> None:
+        self.robot_locomotion = QuadrupedRobotVerticalOVOmni()
+        self.robot_manipulation = QuadrupedRobotVerticalOVFixedOmni()
+        rd = self.robot_manipulation.robot_description
+        rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = list(self.mani_base_position)
+        _QuadrupedTask.__init__(self, sim_config, name, env, offset)
+        self._single_task_num_envs = self._num_envs // 2
+        assert self._single_task_num_envs * 2 == self._num_envs and self._single_task_num_envs % 16 == 0

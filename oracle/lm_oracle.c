@@ -271,7 +271,9 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     else {
       real d[3], y0[3], y[3]; for (int a=0;a<3;a++) d[a]=D->tip[i][a]-D->pf[a]; m3Tv(D->Rf, d, y0);
       for (int a=0;a<3;a++) y[a]=y0[a]-(real)p->plate_center[a];
-      real sgn = (y[2]>=0)?1:-1; real ez[3]={0,0,sgn}, ex[3]={1,0,0};
+      /* contact face = the slab face on the robot's side of the plate (robust to deep initial overlap) */
+      real db[3], yb[3]; for (int a=0;a<3;a++) db[a]=D->p0[a]-D->pf[a]; m3Tv(D->Rf, db, yb);
+      real sgn = (yb[2]-(real)p->plate_center[2]>=0)?1:-1; real ez[3]={0,0,sgn}, ex[3]={1,0,0};
       m3v(D->Rf, ez, n); m3v(D->Rf, ex, t1); cross(n, t1, t2);
       phi = sgn*y[2]-(real)p->plate_half[2]-(real)p->tip_radius;
       if (fabs(y[0])>(real)p->plate_half[0] || fabs(y[1])>(real)p->plate_half[1]) phi = 1.0e3;
@@ -325,6 +327,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
 }
 
 void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets) {
+  #pragma omp parallel for schedule(static)
   for (int e=0;e<N;e++) substep_one(m, p, phys+(size_t)e*LMO_PHYS, targets+(size_t)e*12);
 }
 
@@ -333,6 +336,7 @@ static void quat_rotate_inverse(const real* q, const real* v, real* o) { real R[
 
 void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real* actions,
                    real* task, int64_t* cnt, real* obs, real* states, real* rew, real* terms) {
+  #pragma omp parallel for schedule(static)
   for (int e=0;e<N;e++) {
     const real* rb=readback+(size_t)e*LMO_READBACK; const real* act=actions+(size_t)e*12;
     real* tk=task+(size_t)e*LMO_TASK; int64_t* c=cnt+(size_t)e*LMO_CNT;
@@ -469,6 +473,7 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
   /* robot.py:452-454: velocity mode, unscale_transform(a, -lim, +lim) = a*lim */
   for (size_t i=0;i<(size_t)N*12;i++) targets[i]=actions[i]*(real)p->act_scale;
   for (int s=0;s<p->substeps;s++) lmo_substep(m, p, N, phys, targets);
+  #pragma omp parallel for schedule(static)
   for (int e=0;e<N;e++) {
     real* ph=phys+(size_t)e*LMO_PHYS; real* tk=task+(size_t)e*LMO_TASK; real* r=rb+(size_t)e*LMO_READBACK;
     for (int i=0;i<12;i++) { r[i]=ph[13+i]; r[12+i]=ph[25+i];

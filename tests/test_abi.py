@@ -1,0 +1,67 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/lm_engine.h declares, the
+ctypes mirror of lm_params has the C layout, and argument validation returns error codes (no exceptions /
+crashes across the ABI)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+from locomanipulationrl_amd import lib as lmlib
+
+HEADER = os.path.join(ROOT, "include", "lm_engine.h")
+
+
+@pytest.fixture(scope="module")
+def so():
+    lmlib.build_library()
+    return lmlib.load_library()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_exports_match_header(so):
+    names = declared_symbols()
+    assert set(names) == set(lmlib.EXPORTS), (names, lmlib.EXPORTS)
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in lm_engine.h but not exported"
+    assert b"gfx950" in so.lm_version()
+
+
+def test_params_struct_layout_matches_c():
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "lm_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(lm_params), ' \
+          'offsetof(lm_params, substeps), offsetof(lm_params, init_q), offsetof(lm_params, corner), offsetof(lm_params, plate_phi));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c"); open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        size, o_sub, o_q, o_corner, o_phi = map(int, subprocess.check_output([exe]).split())
+    P = lmlib.LmParams
+    assert C.sizeof(P) == size
+    assert (P.substeps.offset, P.init_q.offset, P.corner.offset, P.plate_phi.offset) == (o_sub, o_q, o_corner, o_phi)
+
+
+def test_argument_validation_without_gpu(so):
+    h = C.c_void_p()
+    assert so.lm_create(C.byref(h), 0, None, None, 1, 0, 0) == -1            # LM_EINVAL: null table/params
+    assert b"null" in so.lm_last_error()
+    assert so.lm_step(None, None, None, None, None, None, None, None, None) == -1
+    assert so.lm_reset_all(None, None) == -1
+    assert so.lm_num_envs(None) == 0 and so.lm_ptr(None, 0) is None
+    assert so.lm_destroy(None) == 0
+    import numpy as np
+    from locomanipulationrl_amd.engine_config import loco_params
+    tab = np.zeros(lmlib.TABLE_FLOATS, np.float32)
+    arr = (lmlib.LmParams * 2)(lmlib.make_params(loco_params()), lmlib.make_params(loco_params()))
+    assert so.lm_create(C.byref(h), -5, tab.ctypes.data_as(C.c_void_p), arr, 1, 0, 0) == -1
+    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), arr, 3, 0, 0) == -1
+    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), arr, 2, 24, 0) == -1     # split not a multiple of 16
+    bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(dt=0.0)))
+    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1

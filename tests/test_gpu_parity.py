@@ -1,0 +1,244 @@
+"""GPU parity: the HIP engine (through the C ABI) against the float64 CPU oracle on identical seeded inputs,
+against the golden vectors captured from the reference's Python, and -- at BASELINE.json's full size --
+through size-independent invariants.
+
+Tolerances (fp32 kernel vs fp64 oracle; written here as the contract):
+  kinematics (tips, knees)                     1e-6 m
+  dynamics terms M / h                          2e-6 / 2e-5 absolute (entries up to 2.3 / 23)
+  one physics sub-step, joint velocities        3e-4 rad/s absolute (values up to ~6), poses 1e-6
+  one control step (4 sub-steps) observations   5e-3 absolute on >= 99 % of the envs: the torque clamp and the
+      contact complementarity are branch points, so an env sitting on a threshold may take the other branch in
+      fp32; such envs are counted, bounded to 1 %, and excluded from the max-norm.
+  task layer vs reference golden vectors        2e-5 on observations, 1e-5 relative on rewards (exact on integers)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from locomanipulationrl_amd.engine_config import loco_params, mani_params
+
+pytestmark = pytest.mark.gpu
+
+
+def qmul(a, b):
+    w1, x1, y1, z1 = a.T; w2, x2, y2, z2 = b.T
+    return np.stack([w1*w2-x1*x2-y1*y2-z1*z2, w1*x2+x1*w2+y1*z2-z1*y2, w1*y2-x1*z2+y1*w2+z1*x2, w1*z2+x1*y2-y1*x2+z1*w2], 1)
+
+
+def rand_states(o, N, rng, mode):
+    phys, task, cnt = o.new_state(N)
+    o.reset(phys, task, cnt, seed=1)
+    phys[:, 13:25] += rng.normal(size=(N, 12)) * 0.15
+    phys[:, 25:37] = rng.normal(size=(N, 12)) * 1.0
+    fb = 0 if mode == 0 else 37
+    phys[:, fb + 7:fb + 13] = rng.normal(size=(N, 6)) * 0.3
+    qq = np.concatenate([np.ones((N, 1)), rng.normal(size=(N, 3)) * 0.1], 1)
+    base = np.array([1, 0, 0, 0.]) if mode == 0 else np.array([0, 1, 0, 0.])
+    phys[:, fb + 3:fb + 7] = qmul(qq / np.linalg.norm(qq, axis=1, keepdims=True), np.tile(base, (N, 1)))
+    if mode == 0:
+        phys[:, 2] = 0.128 + rng.normal(size=N) * 0.004
+    else:
+        phys[:, 39] = 0.134 + rng.normal(size=N) * 0.003
+        phys[:, 37:39] = rng.normal(size=(N, 2)) * 0.01
+    return phys, task, cnt
+
+
+@pytest.fixture(scope="module")
+def engine_cls():
+    from locomanipulationrl_amd.lib import Engine, build_library
+    build_library()
+    return Engine
+
+
+@pytest.fixture(scope="module")
+def oracle_cls():
+    from oracle.lmo import Oracle
+    return Oracle
+
+
+def outs(N):
+    return (torch.empty(N, 64, device="cuda"), torch.empty(N, 93, device="cuda"), torch.empty(N, device="cuda"),
+            torch.empty(N, dtype=torch.int64, device="cuda"), torch.empty(8, device="cuda"))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N", [16, 50])          # 50: ragged last wavefront (2 envs)
+def test_kinematics_and_substep_parity(robot_model, engine_cls, oracle_cls, mode, N):
+    ep = loco_params() if mode == 0 else mani_params()
+    o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N)
+    rng = np.random.default_rng(10 + mode)
+    phys, task, cnt = rand_states(o, N, rng, mode)
+    eng.set_phys_env_major(phys)
+    tips, knees = eng.forward_kinematics(); ot, ok = o.fk(phys)
+    assert np.abs(tips.cpu().numpy() - ot).max() < 1e-6 and np.abs(knees.cpu().numpy() - ok).max() < 1e-6
+    if mode == 0:
+        M, h = eng.debug_dynamics(); M, h = M.cpu().numpy(), h.cpu().numpy()
+        for e in range(N):
+            Mo, ho = o.dyn_terms(phys[e])
+            assert np.abs(M[e] - Mo).max() < 2e-6 and np.abs(h[e] - ho).max() < 2e-5
+    tg = rng.uniform(-3, 3, size=(N, 12))
+    p2 = phys.copy(); o.substep(p2, tg)
+    eng.substeps(torch.as_tensor(tg, dtype=torch.float32, device="cuda"), 1)
+    g = eng.get_phys_env_major(); fb = 0 if mode == 0 else 37
+    assert np.abs(g[:, fb:fb + 7] - p2[:, fb:fb + 7]).max() < 1e-6
+    assert np.abs(g[:, 13:25] - p2[:, 13:25]).max() < 3e-6
+    assert np.abs(g[:, 25:37] - p2[:, 25:37]).max() < 3e-4
+    assert np.abs(g[:, fb + 7:fb + 13] - p2[:, fb + 7:fb + 13]).max() < 1e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_contact_free_dynamics_tight(robot_model, engine_cls, oracle_cls, mode):
+    """Without contact and without torque saturation there is no branch point: 4 sub-steps agree to rounding."""
+    ep = (loco_params if mode == 0 else mani_params)(tau_max=1e9)
+    N = 32; o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N)
+    rng = np.random.default_rng(3)
+    phys, task, cnt = rand_states(o, N, rng, mode)
+    if mode == 0: phys[:, 2] = 1.0
+    else: phys[:, 39] = 1.0
+    tg = rng.uniform(-3, 3, size=(N, 12)); p2 = phys.copy(); eng.set_phys_env_major(phys)
+    for _ in range(4): o.substep(p2, tg)
+    eng.substeps(torch.as_tensor(tg, dtype=torch.float32, device="cuda"), 4)
+    g = eng.get_phys_env_major()
+    assert np.abs(g[:, :50] - p2[:, :50]).max() < 2e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["loco", "mani"])
+def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
+    g = np.load(os.path.join(GOLDEN, f"task_{kind}.npz"))
+    ep = loco_params() if kind == "loco" else mani_params()
+    T, N = g["rew"].shape
+    eng = engine_cls(robot_model, [ep], N)
+    for t in range(T):
+        eng.apply_resets(torch.as_tensor(g["goal_rand"][t], device="cuda"))
+        o = outs(N)
+        eng.task_eval(torch.as_tensor(g["readback"][t], device="cuda").contiguous(), torch.as_tensor(g["actions"][t], device="cuda"), *o)
+        torch.cuda.synchronize()
+        obs, states, rew, resets, extras = [x.cpu().numpy() for x in o]
+        assert np.abs(obs - np.clip(g["obs"][t], -5, 5)).max() < 2e-5
+        assert np.abs(states - np.clip(g["states"][t], -5, 5)).max() < 2e-5
+        assert np.abs(eng.obs_buf.cpu().numpy() - g["obs"][t]).max() < 2e-5          # task.obs_buf is unclipped
+        assert np.allclose(rew, g["rew"][t], rtol=1e-5, atol=2e-5)
+        cnt = eng.get_cnt_env_major()
+        assert np.array_equal(resets, g["reset_buf"][t])
+        for name, col in (("successes", 0), ("consecutive_successes", 1), ("goal_reset_buf", 2), ("reset_buf", 3), ("progress_buf", 4)):
+            assert np.array_equal(cnt[:, col], g[name][t]), (name, t)
+        task = eng.get_task_env_major()
+        assert np.abs(task[:, 0:12] - g["last_actions"][t]).max() == 0
+        assert np.abs(task[:, 24:36] - g["last_base_tip"][t]).max() < 2e-6
+        assert np.abs(task[:, 36:40] - g["goal_quaternions"][t]).max() < 1e-6
+        ref = {str(k): v for k, v in zip(g["extras_keys"], g["extras"][t])}
+        mine = dict(zip(["env/rewards/orientation_rew", "env/rewards/translation_penalty", "env/rewards/joint_acc_penalty",
+                         "env/rewards/action_rate_penalty", "env/rewards/consecutive_successes_rew", "env/rewards/joint_limit_panelty",
+                         "env/rewards/fall_penalty", "env/success_rate"], extras))
+        for k, v in ref.items():
+            assert abs(mine[k] - v) < 1e-5 * max(1.0, abs(v)), (k, t)
+        st = eng.stats_i64.cpu().numpy()
+        assert st[0] == g["num_successes"][t] and st[1] == g["num_resets"][t]
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_full_step_parity_from_identical_states(robot_model, engine_cls, oracle_cls, mode):
+    ep = loco_params() if mode == 0 else mani_params()
+    N = 256; o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N, seed=42)
+    rng = np.random.default_rng(5)
+    phys, task, cnt = o.new_state(N)
+    bad_total = 0
+    for t in range(5):
+        # both sides start every step from the oracle's state (the dynamics amplify rounding ~10x per step)
+        eng.set_phys_env_major(phys); eng.set_task_env_major(task); eng.set_cnt_env_major(cnt)
+        act = rng.uniform(-1.2, 1.2, size=(N, 12)).astype(np.float32)
+        # the +-clipActions clamp of VecEnvRLGames.step (vec_env_rlgames.py:60) happens inside lm_step
+        obs, states, rew, terms = o.step(phys, task, cnt, np.clip(act, -1, 1).astype(np.float64), seed=42)
+        out = outs(N); eng.step(torch.as_tensor(act, device="cuda"), None, *out); torch.cuda.synchronize()
+        gobs, gst, grew, grs, gex = [x.cpu().numpy() for x in out]
+        d = np.abs(gobs - np.clip(obs, -5, 5)).max(1)
+        bad = d > 5e-3
+        bad_total += int(bad.sum())
+        ok = ~bad
+        assert np.abs(gst[ok] - np.clip(states[ok], -5, 5)).max() < 5e-3
+        assert np.abs(grew[ok] - rew[ok]).max() < 5e-3 * max(1.0, np.abs(rew).max())
+        assert (grs[ok] != cnt[ok, 3]).mean() < 0.01
+        c2 = eng.get_cnt_env_major()
+        assert np.array_equal(c2[:, 4], cnt[:, 4]) and np.array_equal(c2[:, 5], cnt[:, 5])
+        assert np.abs(eng.get_task_env_major()[:, 36:40] - task[:, 36:40]).max() < 1e-6     # same goals: the hash RNG is bit-exact
+    assert bad_total <= 0.01 * 5 * N, bad_total
+    eng.close()
+
+
+def test_hash_rng_bit_exact(robot_model, engine_cls, oracle_cls):
+    ep = loco_params(); N = 64
+    o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N, seed=1234)
+    eng.apply_resets(None)
+    goal = eng.get_task_env_major()[:, 36:40]
+    phys, task, cnt = o.new_state(N); o.reset(phys, task, cnt, seed=1234)
+    assert np.abs(goal - task[:, 36:40]).max() < 2e-7
+    assert np.array_equal(eng.get_cnt_env_major()[:, 5], np.ones(N, np.int64))
+    eng.close()
+
+
+def test_full_size_invariants_4096(robot_model, engine_cls):
+    """BASELINE config 2 (4096 envs): size-independent properties over 400 random-action steps."""
+    N = 4096; eng = engine_cls(robot_model, [loco_params()], N, seed=42)
+    g = torch.Generator(device="cuda").manual_seed(42)
+    total_resets = 0
+    for t in range(400):
+        a = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1
+        out = outs(N); eng.step(a, None, *out)
+        if t % 50 == 49:
+            obs, st, rew, rs, ex = out
+            assert torch.isfinite(obs).all() and torch.isfinite(st).all() and torch.isfinite(rew).all()
+            assert obs.abs().max() <= 5.0 and float(rew.min()) > -50 and float(rew.max()) < 610
+            s = eng.state
+            assert (s[3:7].norm(dim=0) - 1).abs().max() < 1e-5 and (s[86:90].norm(dim=0) - 1).abs().max() < 1e-5   # unit quaternions
+            assert torch.isfinite(s).all()
+            c = eng.cnt
+            assert int(c[4].max()) <= 299 and int(c[4].min()) >= 1 and int(c[1].max()) <= 17
+            assert torch.equal(rs, c[3])
+            total_resets += int(rs.sum())
+            assert abs(float(ex[0]) - float(eng.terms[0].mean())) < 1e-5          # extras are the means of the per-env terms
+    assert total_resets > 0
+    eng.close()
+
+
+def test_determinism_and_staged_equals_fused(robot_model, engine_cls):
+    N = 512; ep = loco_params()
+    e1 = engine_cls(robot_model, [ep], N, seed=7); e2 = engine_cls(robot_model, [ep], N, seed=7); e3 = engine_cls(robot_model, [ep], N, seed=7)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(20):
+        a = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1
+        # the staged path hands the state through HBM in world coordinates between sub-steps (rounding-level
+        # differences that the contact dynamics amplify), so it restarts from the fused engine's state every step
+        e3.state.copy_(e1.state); e3.cnt.copy_(e1.cnt)
+        o1, o2, o3 = outs(N), outs(N), outs(N)
+        e1.step(a, None, *o1); e2.step(a, None, *o2)
+        e3.apply_resets(None); e3.substeps((a.clamp(-1, 1) * 3.0).contiguous(), 4); e3.post_physics(a, *o3)
+        for x, y in zip(o1, o2):
+            assert torch.equal(x, y), "bitwise reproducible (fixed-order reductions, no float atomics)"
+        bad = ((o1[0] - o3[0]).abs().max(dim=1).values > 2e-3)
+        assert float(bad.float().mean()) <= 0.02, "staged pre/world/post path == fused step"
+        assert float((o1[3] != o3[3]).float().mean()) <= 0.02
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.cnt, e2.cnt)
+    for e in (e1, e2, e3): e.close()
+
+
+def test_cotrain_two_task_engine(robot_model, engine_cls, oracle_cls):
+    """First half locomotion, second half manipulation in ONE launch (joint_locomanipulation.py:25-34)."""
+    N = 64; pl, pm = loco_params(), mani_params()
+    eng = engine_cls(robot_model, [pl, pm], N, split_env=32, seed=9)
+    ol, om = oracle_cls(robot_model, pl), oracle_cls(robot_model, pm)
+    rng = np.random.default_rng(1); act = rng.uniform(-1, 1, size=(N, 12)).astype(np.float32)
+    out = outs(N); eng.step(torch.as_tensor(act, device="cuda"), None, *out); torch.cuda.synchronize()
+    obs = out[0].cpu().numpy()
+    for o, sl in ((ol, slice(0, 32)), (om, slice(32, 64))):
+        phys, task, cnt = o.new_state(32)
+        gr = np.stack([o.hash_uniform3(9, e, 0) for e in range(sl.start, sl.stop)])
+        ob, st, rw, tr = o.step(phys, task, cnt, act[sl].astype(np.float64), goal_rand=gr)
+        d = np.abs(obs[sl] - np.clip(ob, -5, 5)).max(1)
+        assert (d < 5e-3).mean() >= 0.9 and np.median(d) < 2e-4, d      # branch-point envs excepted (module docstring)
+    eng.close()
