@@ -1,0 +1,113 @@
+"""Weak pins of the physics specification ("what pins the physics instead"): conservation laws with
+first-order convergence, analytic free fall, standing stability, and the envelope of the reference's recorded
+PhysX joint trajectories (row 0 of RL/tasks/joint_train_locomanipulation/*.npy, extracted into
+tests/golden/npy_row0.npz).  PhysX itself cannot be run: parity against it is UNPINNED."""
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from locomanipulationrl_amd.engine_config import loco_params, mani_params
+from oracle.lmo import Oracle
+
+
+def quat2mat(q):
+    w, x, y, z = q
+    return np.array([[1-2*(y*y+z*z), 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), 1-2*(x*x+z*z), 2*(y*z-w*x)], [2*(x*z-w*y), 2*(y*z+w*x), 1-2*(x*x+y*y)]])
+
+
+def momentum_energy(o, ph):
+    M, h = o.dyn_terms(ph); R = quat2mat(ph[3:7])
+    u = np.concatenate([R.T @ ph[10:13], R.T @ ph[7:10], ph[25:37]])
+    hb = M[:6] @ u; n, f = R @ hb[:3], R @ hb[3:]
+    return np.concatenate([n + np.cross(ph[:3], f), f]), 0.5 * u @ M @ u
+
+
+def test_free_flight_conserves_momentum_and_energy_first_order(robot_model):
+    errs = []
+    for dt in (1e-3, 1e-4):
+        o = Oracle(robot_model, loco_params(dt=dt, kd=0.0, gravity=0.0))
+        phys, task, cnt = o.new_state(1); o.reset(phys, task, cnt)
+        rng = np.random.default_rng(0)
+        phys[0, 2] = 5.0; phys[0, 7:13] = rng.normal(size=6) * 0.5; phys[0, 25:37] = rng.normal(size=12) * 2
+        m0, e0 = momentum_energy(o, phys[0])
+        for _ in range(int(0.2 / dt)):
+            o.substep(phys, np.zeros((1, 12)))
+        m1, e1 = momentum_energy(o, phys[0])
+        errs.append((np.abs(m1 - m0).max(), abs(e1 - e0) / e0))
+    assert errs[0][0] < 2e-3 and errs[0][1] < 5e-4
+    assert errs[1][0] < errs[0][0] / 5 and errs[1][1] < errs[0][1] / 5            # O(dt) convergence
+
+
+def test_free_fall_is_analytic(robot_model):
+    o = Oracle(robot_model, loco_params())
+    phys, task, cnt = o.new_state(1); o.reset(phys, task, cnt); phys[0, 2] = 10.0
+    n = 40
+    for _ in range(n):
+        o.substep(phys, np.zeros((1, 12)))
+    t = n * 0.0083
+    assert abs(phys[0, 9] + 9.81 * t) < 1e-6                                       # v_z = -g t exactly (semi-implicit Euler)
+    assert abs(phys[0, 2] - (10.0 - 9.81 * 0.0083 ** 2 * n * (n + 1) / 2)) < 1e-6
+    assert np.abs(phys[0, 3:7] - [1, 0, 0, 0]).max() < 1e-6                        # zero-velocity drive holds the limbs: no tumbling
+
+
+def test_standing_is_stable(robot_model):
+    ep = loco_params(); o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(4); o.reset(phys, task, cnt)
+    for _ in range(300):
+        o.substep(phys, np.zeros((4, 12)))
+    tips, knees = o.fk(phys)
+    assert np.abs(tips[:, :, 2] - ep.tip_radius).max() < 1e-3                      # feet rest on the ground
+    assert 0.12 < phys[0, 2] < 0.14 and np.abs(phys[:, 7:13]).max() < 0.02        # base settled ~0.131 m
+    assert np.abs(phys[:, 13:25] - np.array(ep.init_q)).max() < 0.03               # velocity servo creeps slowly under load
+    assert knees[:, :, 2].min() > 0.04 and np.abs(phys[:, 3:7] - [1, 0, 0, 0]).max() < 0.01
+
+
+def test_plate_rests_on_inverted_robot(robot_model):
+    ep = mani_params(); o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(2); o.reset(phys, task, cnt)
+    for _ in range(300):
+        o.substep(phys, np.zeros((2, 12)))
+    tips, _ = o.fk(phys)
+    # flipped plate (quat [0,1,0,0]): its lower world face is plate-frame z = 0.008
+    assert np.abs((phys[:, 39] - 0.008) - (tips[:, :, 2].mean(1) + ep.tip_radius)).max() < 1.5e-3
+    assert np.abs(phys[:, 44:50]).max() < 0.02 and np.abs(phys[:, 37:39]).max() < 5e-3
+
+
+def test_reference_npy_row0_envelope(robot_model):
+    """One control period after reset the reference's PhysX joints sit within 4.2e-3 rad (loco) / 1.3e-2 rad (mani) of
+    init_joint_pos.  The recordings were made under an unknown first policy action, so this is an envelope:
+    ours under zero action must stay inside it and near the recorded values."""
+    g = np.load(os.path.join(GOLDEN, "npy_row0.npz"))
+    init = np.array([-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92])
+    loco = g["mlp_joint_loco"]; mani = g["mlp_joint_mani"]
+    assert np.abs(loco - init).max() < 4.5e-3 and np.abs(mani - init).max() < 1.3e-2
+    # co-train poses: loco base z 0.18 (quadruped_robot.py:53), mani base z 0.5 inverted + plate z 0.68 (joint_locomanipulation.py:139,198)
+    pl = loco_params(init_q=list(init), init_base_pos=[0, 0, 0.18])
+    pm = mani_params(init_q=list(init), fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])
+    for ep, ref, tol in ((pl, loco, 5e-3), (pm, mani, 2.5e-2)):
+        o = Oracle(robot_model, ep)
+        phys, task, cnt = o.new_state(1)
+        o.step(phys, task, cnt, np.zeros((1, 12)), seed=0)
+        assert np.abs(phys[0, 13:25] - init).max() < tol
+        assert np.abs(phys[0, 13:25] - ref).max() < tol + 3e-3
+        assert np.abs(phys[0, 13:25]).max() < np.pi
+
+
+def test_saturated_drive_respects_torque_limit(robot_model):
+    """A target far from the joint velocity saturates the drive: the velocity change per sub-step is bounded by
+    tau_max * dt / (smallest joint-space inertia), not by the 100 N m s/rad gain."""
+    ep = loco_params(); o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(1); o.reset(phys, task, cnt); phys[0, 2] = 5.0
+    M, _ = o.dyn_terms(phys[0])
+    o.substep(phys, np.full((1, 12), 3.0))
+    dv = np.abs(phys[0, 25:37])
+    assert dv.max() < 3.0                                                      # did not jump to the target (it would unsaturated)
+    Minv = np.linalg.inv(M)
+    assert dv.max() <= 1.5 * 0.0083 * np.abs(Minv[6:, 6:]).sum(1).max() * 1.05
+    o2 = Oracle(robot_model, replace(ep, tau_max=1e9))
+    p2, t2, c2 = o2.new_state(1); o2.reset(p2, t2, c2); p2[0, 2] = 5.0
+    o2.substep(p2, np.full((1, 12), 3.0))
+    assert np.abs(p2[0, 25:37] - 3.0).max() < 0.02                             # unsaturated: servo reaches the target in one step
