@@ -59,6 +59,22 @@ LM_DEV void hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, float* 
 #pragma unroll
   for (uint32_t k = 0; k < 3; k++) { uint32_t r = mix32(base + (k + 1U) * 0xC2B2AE35U); u[k] = (float)(r >> 8) * (1.0f / 16777216.0f); }
 }
+// sin/cos for |x| up to a few turns (joint angles are bounded by +-pi): Cody-Waite reduction to [-pi/4, pi/4] and
+// the single-precision minimax polynomials of Cephes sinf/cosf; absolute error ~1e-7, ~25 instructions
+// (the libm sincosf carries a large-argument Payne-Hanek path that costs ~150).
+LM_DEV void lm_sincos(float x, float* s, float* c) {
+  float kf = rintf(x * 0.636619772367581343f);          // 2/pi
+  int k = (int)kf;
+  float r = fmaf(-kf, 1.57079625129699707031f, x);       // pi/2 split in three parts
+  r = fmaf(-kf, 7.54978941586159635335e-8f, r);
+  r = fmaf(-kf, 5.39030285815811905290e-15f, r);
+  float z = r * r;
+  float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  float ss = (k & 1) ? cp : sp, cc = (k & 1) ? sp : cp;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
 LM_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
   float sy, cy, sr, cr, sp, cp;
   sincosf(yaw * 0.5f, &sy, &cy); sincosf(roll * 0.5f, &sr, &cr); sincosf(pitch * 0.5f, &sp, &cp);
@@ -110,7 +126,7 @@ struct LimbKin {
 
 LM_DEV void limb_kinematics(const float* tl, const float q[3], const float qd[3], LimbKin& K) {
   float s1_, c1_, s2_, c2_, s3_, c3_;
-  sincosf(q[0], &s1_, &c1_); sincosf(q[1], &s2_, &c2_); sincosf(q[2], &s3_, &c3_);
+  lm_sincos(q[0], &s1_, &c1_); lm_sincos(q[1], &s2_, &c2_); lm_sincos(q[2], &s3_, &c3_);
   float cD = c2_ * c3_ + s2_ * s3_, sD = s2_ * c3_ - c2_ * s3_;      // D = q2 - q3
   float inv = 1.0f / (3.0f - cD);
   float cp = (3.0f * cD - 1.0f) * inv, sp = 2.0f * SQRT2F * sD * inv;
@@ -174,40 +190,68 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
   D.x = K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117]));
 }
 
-// projected Gauss-Seidel over the 4 tip contacts of one env; lanes take turns (limb 0..3), the hub/plate
-// velocity change w is kept identical in the 4 lanes.
+// Projected Gauss-Seidel over the 4 tip contacts of one env (rows n, t1, t2 per contact, limb order).
+// The Delassus operator is  W_ij = delta_ij D_i + T_i^T Phi T_j  (arrowhead structure of the hub + limbs system).
+// Each lane keeps the current contact-space velocity c (3) of ITS contact, its own full 3x3 block, and the 3x3
+// cross blocks X_K = T_i^T B_K towards the other three contacts; lanes take turns, the lane whose turn it is
+// relaxes its three rows, then its three impulse increments are quad-broadcast and every other lane updates c
+// with 9 FMAs.  Identical arithmetic (up to rounding) to row-wise PGS on the dense 12x12 system of the oracle.
+struct PgsData { float Wf[6]; float rW[3]; float X[4][9]; };
+
 template <int K>
-LM_DEV void pgs_turn(int limb, float mu, float bn, const float vf[3], const float Wl[6], const float rW[3],
-                     const SV T[3], const SV B[3], float lam[3], SV& w) {
-  SV wl = w;
-  float v = vf[0] + bn + Wl[0] * lam[0] + Wl[1] * lam[1] + Wl[2] * lam[2] + sdot(T[0], wl);
-  float ln = fmaxf(0.0f, lam[0] - v * rW[0]);
-  wl = fma6(ln - lam[0], B[0], wl);
-  float lim = mu * ln;
-  v = vf[1] + Wl[1] * ln + Wl[3] * lam[1] + Wl[4] * lam[2] + sdot(T[1], wl);
-  float l1 = fminf(lim, fmaxf(-lim, lam[1] - v * rW[1]));
-  wl = fma6(l1 - lam[1], B[1], wl);
-  v = vf[2] + Wl[2] * ln + Wl[4] * l1 + Wl[5] * lam[2] + sdot(T[2], wl);
-  float l2 = fminf(lim, fmaxf(-lim, lam[2] - v * rW[2]));
-  wl = fma6(l2 - lam[2], B[2], wl);
-  SV dw = wl - w;
-  w.w.x += quad_bcast<K>(dw.w.x); w.w.y += quad_bcast<K>(dw.w.y); w.w.z += quad_bcast<K>(dw.w.z);
-  w.v.x += quad_bcast<K>(dw.v.x); w.v.y += quad_bcast<K>(dw.v.y); w.v.z += quad_bcast<K>(dw.v.z);
-  bool mine = (limb == K);
-  lam[0] = mine ? ln : lam[0]; lam[1] = mine ? l1 : lam[1]; lam[2] = mine ? l2 : lam[2];
+LM_DEV void pgs_cross_blocks(int limb, const SV T[3], const SV B[3], float X[9]) {
+  SV Bk[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    Bk[s].w = v3(quad_bcast<K>(B[s].w.x), quad_bcast<K>(B[s].w.y), quad_bcast<K>(B[s].w.z));
+    Bk[s].v = v3(quad_bcast<K>(B[s].v.x), quad_bcast<K>(B[s].v.y), quad_bcast<K>(B[s].v.z));
+  }
+  const float keep = (limb == K) ? 0.f : 1.f;      // the own block is applied through Wf
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) X[3 * r + s] = keep * sdot(T[r], Bk[s]);
+}
+
+template <int K>
+LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float lam[3], float c[3]) {
+  const bool mine = (limb == K);
+  float ln = fmaxf(0.0f, lam[0] - c[0] * G.rW[0]);
+  float d0 = mine ? (ln - lam[0]) : 0.f;
+  lam[0] += d0; c[0] = fmaf(G.Wf[0], d0, c[0]); c[1] = fmaf(G.Wf[1], d0, c[1]); c[2] = fmaf(G.Wf[2], d0, c[2]);
+  float lim = mu * lam[0];
+  float l1 = fminf(lim, fmaxf(-lim, lam[1] - c[1] * G.rW[1]));
+  float d1 = mine ? (l1 - lam[1]) : 0.f;
+  lam[1] += d1; c[0] = fmaf(G.Wf[1], d1, c[0]); c[1] = fmaf(G.Wf[3], d1, c[1]); c[2] = fmaf(G.Wf[4], d1, c[2]);
+  float l2 = fminf(lim, fmaxf(-lim, lam[2] - c[2] * G.rW[2]));
+  float d2 = mine ? (l2 - lam[2]) : 0.f;
+  lam[2] += d2; c[0] = fmaf(G.Wf[2], d2, c[0]); c[1] = fmaf(G.Wf[4], d2, c[1]); c[2] = fmaf(G.Wf[5], d2, c[2]);
+  float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d1), b2 = quad_bcast<K>(d2);
+  const float* X = G.X[K];
+  c[0] = fmaf(X[0], b0, fmaf(X[1], b1, fmaf(X[2], b2, c[0])));
+  c[1] = fmaf(X[3], b0, fmaf(X[4], b1, fmaf(X[5], b2, c[1])));
+  c[2] = fmaf(X[6], b0, fmaf(X[7], b1, fmaf(X[8], b2, c[2])));
 }
 
 LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3], const float Wl[6],
                       const SV T[3], const SV B[3], float lam[3], SV& w) {
-  // full Delassus diagonal = limb-local part + hub/plate part T_r^T Phi T_r
-  float rW[3] = {1.0f / (Wl[0] + sdot(T[0], B[0])), 1.0f / (Wl[3] + sdot(T[1], B[1])), 1.0f / (Wl[5] + sdot(T[2], B[2]))};
-  lam[0] = lam[1] = lam[2] = 0.f; w = sv(v3(0, 0, 0), v3(0, 0, 0));
+  PgsData G;
+  // full own block = limb-local part + hub/plate part T_r^T Phi T_s
+  G.Wf[0] = Wl[0] + sdot(T[0], B[0]); G.Wf[1] = Wl[1] + sdot(T[0], B[1]); G.Wf[2] = Wl[2] + sdot(T[0], B[2]);
+  G.Wf[3] = Wl[3] + sdot(T[1], B[1]); G.Wf[4] = Wl[4] + sdot(T[1], B[2]); G.Wf[5] = Wl[5] + sdot(T[2], B[2]);
+  G.rW[0] = 1.0f / G.Wf[0]; G.rW[1] = 1.0f / G.Wf[3]; G.rW[2] = 1.0f / G.Wf[5];
+  pgs_cross_blocks<0>(limb, T, B, G.X[0]); pgs_cross_blocks<1>(limb, T, B, G.X[1]);
+  pgs_cross_blocks<2>(limb, T, B, G.X[2]); pgs_cross_blocks<3>(limb, T, B, G.X[3]);
+  lam[0] = lam[1] = lam[2] = 0.f;
+  float c[3] = {vf[0] + bn, vf[1], vf[2]};
   for (int it = 0; it < iters; it++) {
-    pgs_turn<0>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
-    pgs_turn<1>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
-    pgs_turn<2>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
-    pgs_turn<3>(limb, mu, bn, vf, Wl, rW, T, B, lam, w);
+    pgs_turn<0>(limb, mu, G, lam, c);
+    pgs_turn<1>(limb, mu, G, lam, c);
+    pgs_turn<2>(limb, mu, G, lam, c);
+    pgs_turn<3>(limb, mu, G, lam, c);
   }
+  // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
+  w = quad_sum(fma6(lam[0], B[0], fma6(lam[1], B[1], lam[2] * B[2])));
 }
 
 // free rigid body carried as (position, quaternion, body-coordinate spatial velocity about its origin)
@@ -218,7 +262,7 @@ LM_DEV void integrate_free(FreeBody& F, const M3& R, float dt) {
   float wn = sqrtf(dot(ww, ww)), th = wn * dt;
   Q4 dq;
   if (th < 1e-8f) { dq.w = 1.f; dq.x = 0.5f * dt * ww.x; dq.y = 0.5f * dt * ww.y; dq.z = 0.5f * dt * ww.z; }
-  else { float sh, ch; sincosf(0.5f * th, &sh, &ch); float s = sh / wn; dq.w = ch; dq.x = s * ww.x; dq.y = s * ww.y; dq.z = s * ww.z; }
+  else { float sh, ch; lm_sincos(0.5f * th, &sh, &ch); float s = sh / wn; dq.w = ch; dq.x = s * ww.x; dq.y = s * ww.y; dq.z = s * ww.z; }
   Q4 qn = qmul(dq, F.q);
   float rn = rsqrtf(qn.w * qn.w + qn.x * qn.x + qn.y * qn.y + qn.z * qn.z);
   F.q.w = qn.w * rn; F.q.x = qn.x * rn; F.q.y = qn.y * rn; F.q.z = qn.z * rn;

@@ -255,6 +255,9 @@ static void chol_solve(real L[NU][NU], const real* b, real* x) {
   for (int i=NU-1;i>=0;i--) { real s=y[i]; for (int k=i+1;k<NU;k++) s-=L[k][i]*x[k]; x[i]=s/L[i][i]; }
 }
 
+/* debug capture of the contact problem of the LAST pass executed (tests / solver studies) */
+static __thread real* g_cap_W = 0; static __thread real* g_cap_vf = 0; static __thread real* g_cap_bn = 0; static __thread real* g_cap_lam = 0;
+
 static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, const real* target) {
   dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t));
   dyn_compute(m, p, phys, D);
@@ -297,6 +300,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     for (int r=0;r<12;r++) { chol_solve(L, Jc[r], MiJ[r]); }
     for (int r=0;r<12;r++) { for (int c=0;c<12;c++){ real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*MiJ[c][a]; W[r][c]=s; }
       real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*uf[a]; vf[r]=s; lam[r]=0; }
+    if (g_cap_W) { for (int r=0;r<12;r++) { for (int c=0;c<12;c++) g_cap_W[12*r+c]=W[r][c]; g_cap_vf[r]=vf[r]; } for (int i=0;i<4;i++) g_cap_bn[i]=bn[i]; }
     for (int it=0; it<p->pgs_iters; it++) for (int i=0;i<4;i++) {
       int r=3*i; real v=vf[r]+bn[i]; for (int c=0;c<12;c++) v+=W[r][c]*lam[c];
       real ln=lam[r]-v/W[r][r]; if (ln<0) ln=0; lam[r]=ln;
@@ -304,6 +308,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
         real lt=lam[rr]-vt/W[rr][rr]; real lim=mu*lam[r]; if (lt>lim) lt=lim; if (lt<-lim) lt=-lim; lam[rr]=lt; }
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
+    if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];
     if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); if (tau>tmax){sat[j]=1;tsat[j]=tmax;any=1;} else if (tau<-tmax){sat[j]=1;tsat[j]=-tmax;any=1;} }
       if (!any) break; }
   }
@@ -324,6 +329,14 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     for (int a=0;a<3;a++) { ang[a]=ww[a]; lin[a]=vw[a]; pos[a]+=dt*vw[a]; }
   }
   free(D);
+}
+
+/* one env, one sub-step: the contact problem (W 12x12, vf 12, bn 4) of its last pass and the impulses found (solver studies) */
+void lmo_contact_problem(const lmo_model* m, const lmo_params* p, const real* phys, const real* target, real* W, real* vf, real* bn, real* lam) {
+  real ph[LMO_PHYS]; memcpy(ph, phys, sizeof(ph));
+  g_cap_W=W; g_cap_vf=vf; g_cap_bn=bn; g_cap_lam=lam;
+  substep_one(m, p, ph, target);
+  g_cap_W=0; g_cap_vf=0; g_cap_bn=0; g_cap_lam=0;
 }
 
 void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets) {

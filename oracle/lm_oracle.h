@@ -126,6 +126,10 @@ void lmo_fk(const lmo_model* m, const lmo_params* p, const real* phys, real* tip
 /* one physics sub-step for N envs; targets = joint velocity targets (N x 12) */
 void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets);
 
+/* contact problem of one env's next sub-step: Delassus W (12x12), free contact velocities vf (12), normal biases bn (4)
+ * and the PGS impulses lam (12) -- for solver-convergence studies and tests */
+void lmo_contact_problem(const lmo_model* m, const lmo_params* p, const real* phys, const real* target, real* W, real* vf, real* bn, real* lam);
+
 /* dense dynamics terms of one env (debug/tests): M (18x18 row major), h (18) */
 void lmo_dyn_terms(const lmo_model* m, const lmo_params* p, const real* phys, real* M, real* h);
 
