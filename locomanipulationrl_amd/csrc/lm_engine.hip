@@ -270,103 +270,144 @@ LM_DEV void integrate_free(FreeBody& F, const M3& R, float dt) {
   F.p = fma3(dt, mul(Rn, F.u.v), F.p);
 }
 
+// Per-lane stash in LDS for the pass-invariant terms of a sub-step (they are needed at the top of each of the two
+// drive passes but not during the contact iterations; keeping them in registers across the PGS loop spills).
+// Layout [slot][lane] as float4 -> conflict-free 16-byte accesses.
+#define STASH_SLOTS 22
+struct Stash {
+  float4* base; int lane;
+  LM_DEV void put(int slot, float a, float b, float c, float d) const { base[slot * 64 + lane] = make_float4(a, b, c, d); }
+  LM_DEV float4 get(int slot) const { return base[slot * 64 + lane]; }
+};
+LM_DEV void stash_sv3(const Stash& S, int slot, SV a, SV b, SV c) {      // 18 floats -> 5 slots (last half used)
+  S.put(slot + 0, a.w.x, a.w.y, a.w.z, a.v.x); S.put(slot + 1, a.v.y, a.v.z, b.w.x, b.w.y);
+  S.put(slot + 2, b.w.z, b.v.x, b.v.y, b.v.z); S.put(slot + 3, c.w.x, c.w.y, c.w.z, c.v.x); S.put(slot + 4, c.v.y, c.v.z, 0.f, 0.f);
+}
+LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
+  float4 t0 = S.get(slot), t1 = S.get(slot + 1), t2 = S.get(slot + 2), t3 = S.get(slot + 3), t4 = S.get(slot + 4);
+  a = sv(v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y)); b = sv(v3(t1.z, t1.w, t2.x), v3(t2.y, t2.z, t2.w)); c = sv(v3(t3.x, t3.y, t3.z), v3(t3.w, t4.x, t4.y));
+}
+
 // One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
 // robot base is fixed at (Rb, pb).
 template <int MODE>
-LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb,
+LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb, const Stash& St,
                     FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3]) {
   const float dt = P->dt, kd = P->kd, tmax = P->tau_max;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
-  M3 Rb; V3 pb; SV v0;
-  if (MODE == 0) { Rb = Rf; pb = F.p; v0 = F.u; } else { Rb = Rfix; pb = pfix; v0 = sv(v3(0, 0, 0), v3(0, 0, 0)); }
-  SV avp0 = sv(v3(0, 0, 0), P->gravity * row2(Rb));      // fictitious upward acceleration = gravity
-  LimbKin K; limb_kinematics(tl, q, qd, K);
-  LimbDyn D; limb_dynamics(tl, K, qd, v0, avp0, D);
-
-  // ---- contact geometry of this limb's tip
-  V3 C0, C1, C2;        // contact axes (n, t1, t2) in hub coordinates
-  float bn;             // normal-row bias
-  SV Tp[3];             // MODE 1: T rows (plate side), MODE 0 filled later
-  SV up_free;           // MODE 1: plate free velocity
-  float phi;
-  if (MODE == 0) {
-    C0 = row2(Rb); C1 = row0(Rb); C2 = row1(Rb);
-    phi = pb.z + dot(C0, D.x) - P->tip_radius;
-  } else {
-    V3 xw = pb + mul(Rb, D.x);
-    V3 y0 = mulT(Rf, xw - F.p);
-    V3 y = y0 - v3(P->plate_center[0], P->plate_center[1], P->plate_center[2]);
-    // contact face = the slab face on the robot's side of the plate (robust to deep initial overlap)
-    float sg = (mulT(Rf, pb - F.p).z - P->plate_center[2] >= 0.f) ? 1.f : -1.f;
-    phi = sg * y.z - P->plate_half[2] - P->tip_radius;
-    if (fabsf(y.x) > P->plate_half[0] || fabsf(y.y) > P->plate_half[1]) phi = 1.0e3f;
-    // contact axes in plate coords: n=(0,0,sg) t1=(1,0,0) t2=(0,sg,0); in hub coords: Rb^T Rf axis
-    M3 Mrp = mulTA(Rb, Rf);
-    C0 = sg * Mrp.c2; C1 = Mrp.c0; C2 = sg * Mrp.c1;
-    V3 a0 = v3(0, 0, sg), a1 = v3(1, 0, 0), a2 = v3(0, sg, 0);
-    Tp[0] = sv(-cross(y0, a0), -a0); Tp[1] = sv(-cross(y0, a1), -a1); Tp[2] = sv(-cross(y0, a2), -a2);
-    // plate free motion
-    SI Ip = load_si(P->plate_si);
-    SV hp = fcross(F.u, Ip * F.u);
-    V3 fg = (-P->plate_mass * P->gravity) * row2(Rf);
-    V3 c = v3(P->plate_com[0], P->plate_com[1], P->plate_com[2]);
-    hp = hp - sv(cross(c, fg), fg);
-    float Ph[6][6];
+  float bn;
+  {
+    M3 Rb; V3 pb; SV v0;
+    if (MODE == 0) { Rb = Rf; pb = F.p; v0 = F.u; } else { Rb = Rfix; pb = pfix; v0 = sv(v3(0, 0, 0), v3(0, 0, 0)); }
+    SV avp0 = sv(v3(0, 0, 0), P->gravity * row2(Rb));      // fictitious upward acceleration = gravity
+    LimbKin K; limb_kinematics(tl, q, qd, K);
+    LimbDyn D; limb_dynamics(tl, K, qd, v0, avp0, D);
+    if (MODE == 0) {
+      // the hub body itself rides on limb 0's contribution to the quad reductions
+      const float m0 = (limb == 0) ? 1.f : 0.f;
+      SI I0 = hub_inertia(th);
+      I0.m *= m0; I0.h = m0 * I0.h; I0.xx *= m0; I0.yy *= m0; I0.zz *= m0; I0.xy *= m0; I0.xz *= m0; I0.yz *= m0;
+      D.Isc = D.Isc + I0;
+      D.fcs = D.fcs + I0 * avp0 + fcross(v0, I0 * v0);
+    }
+    // ---- contact geometry of this limb's tip
+    V3 C0, C1, C2;        // contact axes (n, t1, t2) in hub coordinates
+    float phi;
+    if (MODE == 0) {
+      C0 = row2(Rb); C1 = row0(Rb); C2 = row1(Rb);
+      phi = pb.z + dot(C0, D.x) - P->tip_radius;
+    } else {
+      V3 xw = pb + mul(Rb, D.x);
+      V3 y0 = mulT(Rf, xw - F.p);
+      V3 y = y0 - v3(P->plate_center[0], P->plate_center[1], P->plate_center[2]);
+      // contact face = the slab face on the robot's side of the plate (robust to deep initial overlap)
+      float sg = (mulT(Rf, pb - F.p).z - P->plate_center[2] >= 0.f) ? 1.f : -1.f;
+      phi = sg * y.z - P->plate_half[2] - P->tip_radius;
+      if (fabsf(y.x) > P->plate_half[0] || fabsf(y.y) > P->plate_half[1]) phi = 1.0e3f;
+      // contact axes in plate coords: n=(0,0,sg) t1=(1,0,0) t2=(0,sg,0); in hub coords: Rb^T Rf axis
+      M3 Mrp = mulTA(Rb, Rf);
+      C0 = sg * Mrp.c2; C1 = Mrp.c0; C2 = sg * Mrp.c1;
+      V3 a0 = v3(0, 0, sg), a1 = v3(1, 0, 0), a2 = v3(0, sg, 0);
+      SV Tp0 = sv(-cross(y0, a0), -a0), Tp1 = sv(-cross(y0, a1), -a1), Tp2 = sv(-cross(y0, a2), -a2);
+      // plate free motion
+      SI Ip = load_si(P->plate_si);
+      SV hp = fcross(F.u, Ip * F.u);
+      V3 fg = (-P->plate_mass * P->gravity) * row2(Rf);
+      V3 c = v3(P->plate_com[0], P->plate_com[1], P->plate_com[2]);
+      hp = hp - sv(cross(c, fg), fg);
+      float Ph[6][6];
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+      for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = 0; j < 6; j++) Ph[i][j] = P->plate_phi[6 * i + j];
-    up_free = F.u - dt * mul66(Ph, hp);
+        for (int j = 0; j < 6; j++) Ph[i][j] = P->plate_phi[6 * i + j];
+      SV up_free = F.u - dt * mul66(Ph, hp);
+      stash_sv3(St, 12, Tp0, Tp1, Tp2);
+      St.put(17, up_free.w.x, up_free.w.y, up_free.w.z, up_free.v.x); St.put(18, up_free.v.y, up_free.v.z, 0.f, 0.f);
+    }
+    bn = (phi >= 0.f) ? phi / dt : fmaxf(P->baumgarte * phi / dt, -P->max_depen_vel);
+    // tip linear velocity per unit generalized rate, contact coordinates
+    V3 e0 = K.s1.v + cross(K.s1.w, D.x);
+    V3 e1 = D.j31.v + cross(D.j31.w, D.x);
+    V3 e2 = D.j32.v + cross(D.j32.w, D.x);
+    stash_sv3(St, 0, D.Fq0, D.Fq1, D.Fq2);
+    St.put(5, D.H[0], D.H[1], D.H[2], D.H[3]); St.put(6, D.H[4], D.H[5], D.hq[0], D.hq[1]);
+    St.put(7, D.hq[2], dot(C0, e0), dot(C0, e1), dot(C0, e2));
+    St.put(8, dot(C1, e0), dot(C1, e1), dot(C1, e2), dot(C2, e0)); St.put(9, dot(C2, e1), dot(C2, e2), 0.f, 0.f);
+    if (MODE == 0) {
+      St.put(10, D.fcs.w.x, D.fcs.w.y, D.fcs.w.z, D.fcs.v.x); St.put(11, D.fcs.v.y, D.fcs.v.z, D.Isc.m, D.Isc.h.x);
+      St.put(12, D.Isc.h.y, D.Isc.h.z, D.Isc.xx, D.Isc.yy); St.put(13, D.Isc.zz, D.Isc.xy, D.Isc.xz, D.Isc.yz);
+      St.put(14, D.x.x, D.x.y, D.x.z, C0.x); St.put(15, C0.y, C0.z, C1.x, C1.y); St.put(16, C1.z, C2.x, C2.y, C2.z);
+    }
   }
-  bn = (phi >= 0.f) ? phi / dt : fmaxf(P->baumgarte * phi / dt, -P->max_depen_vel);
-  // tip linear velocity per unit generalized rate, contact coordinates
-  V3 e0 = K.s1.v + cross(K.s1.w, D.x);
-  V3 e1 = D.j31.v + cross(D.j31.w, D.x);
-  V3 e2 = D.j32.v + cross(D.j32.w, D.x);
-  float Jq[3][3] = {{dot(C0, e0), dot(C0, e1), dot(C0, e2)}, {dot(C1, e0), dot(C1, e1), dot(C1, e2)}, {dot(C2, e0), dot(C2, e1), dot(C2, e2)}};
-  SV Jb[3] = {sv(cross(D.x, C0), C0), sv(cross(D.x, C1), C1), sv(cross(D.x, C2), C2)};   // MODE 0 hub rows
 
   bool sat[3] = {false, false, false}; float tsat[3] = {0.f, 0.f, 0.f};
   float qdn[3]; SV un;
   for (int pass = 0; pass < 2; pass++) {
-    float Ha[6] = {D.H[0], D.H[1], D.H[2], D.H[3], D.H[4], D.H[5]}, r[3];
+    asm volatile("" ::: "memory");          // keep the stash reloads inside the pass (no hoisting across the PGS loop)
+    SV Fq0, Fq1, Fq2; unstash_sv3(St, 0, Fq0, Fq1, Fq2);
+    float4 h5 = St.get(5), h6 = St.get(6), h7 = St.get(7), h8 = St.get(8), h9 = St.get(9);
+    float Ha[6] = {h5.x, h5.y, h5.z, h5.w, h6.x, h6.y}, r[3];
+    const float hq[3] = {h6.z, h6.w, h7.x};
+    const float Jq[3][3] = {{h7.y, h7.z, h7.w}, {h8.x, h8.y, h8.z}, {h8.w, h9.x, h9.y}};
     const int di[3] = {0, 3, 5};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      if (!sat[a]) { Ha[di[a]] += dt * kd; r[a] = kd * (tgt[a] - qd[a]) - D.hq[a]; }
-      else r[a] = tsat[a] - D.hq[a];
+      if (!sat[a]) { Ha[di[a]] += dt * kd; r[a] = kd * (tgt[a] - qd[a]) - hq[a]; }
+      else r[a] = tsat[a] - hq[a];
     }
     float Hi[6]; inv3sym(Ha, Hi);
     // K = Fq Hinv  (columns)
-    SV K0 = fma6(Hi[0], D.Fq0, fma6(Hi[1], D.Fq1, Hi[2] * D.Fq2));
-    SV K1 = fma6(Hi[1], D.Fq0, fma6(Hi[3], D.Fq1, Hi[4] * D.Fq2));
-    SV K2 = fma6(Hi[2], D.Fq0, fma6(Hi[4], D.Fq1, Hi[5] * D.Fq2));
+    SV K0 = fma6(Hi[0], Fq0, fma6(Hi[1], Fq1, Hi[2] * Fq2));
+    SV K1 = fma6(Hi[1], Fq0, fma6(Hi[3], Fq1, Hi[4] * Fq2));
+    SV K2 = fma6(Hi[2], Fq0, fma6(Hi[4], Fq1, Hi[5] * Fq2));
     float qdd[3], qdf[3]; SV v0f; float Phi[6][6];
+    SV T[3];
     if (MODE == 0) {
-      float A[6][6]; si_to_66(D.Isc, A);
+      float4 g10 = St.get(10), g11 = St.get(11), g12 = St.get(12), g13 = St.get(13);
+      SV fcs = sv(v3(g10.x, g10.y, g10.z), v3(g10.w, g11.x, g11.y));
+      SI Isc; Isc.m = g11.z; Isc.h = v3(g11.w, g12.x, g12.y); Isc.xx = g12.z; Isc.yy = g12.w; Isc.zz = g13.x; Isc.xy = g13.y; Isc.xz = g13.z; Isc.yz = g13.w;
+      float A[6][6]; si_to_66(Isc, A);
       float k0[6], k1[6], k2[6], f0[6], f1[6], f2[6];
-      sv_to_arr(K0, k0); sv_to_arr(K1, k1); sv_to_arr(K2, k2); sv_to_arr(D.Fq0, f0); sv_to_arr(D.Fq1, f1); sv_to_arr(D.Fq2, f2);
+      sv_to_arr(K0, k0); sv_to_arr(K1, k1); sv_to_arr(K2, k2); sv_to_arr(Fq0, f0); sv_to_arr(Fq1, f1); sv_to_arr(Fq2, f2);
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = i; j < 6; j++) A[i][j] = quad_sum(A[i][j] - (k0[i] * f0[j] + k1[i] * f1[j] + k2[i] * f2[j]));
-      SV bA = quad_sum(fma6(r[0], K0, fma6(r[1], K1, fma6(r[2], K2, D.fcs))));
-      // hub body itself
-      SI I0 = hub_inertia(th);
-      float A0[6][6]; si_to_66(I0, A0);
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++) A[i][j] += A0[i][j];
-      bA = bA + I0 * avp0 + fcross(v0, I0 * v0);
+      SV bA = quad_sum(fma6(r[0], K0, fma6(r[1], K1, fma6(r[2], K2, fcs))));
       inv6spd(A, Phi);
       SV a0 = mul66(Phi, sv(-bA.w, -bA.v));
-      float t0 = r[0] - sdot(D.Fq0, a0), t1 = r[1] - sdot(D.Fq1, a0), t2 = r[2] - sdot(D.Fq2, a0);
+      float t0 = r[0] - sdot(Fq0, a0), t1 = r[1] - sdot(Fq1, a0), t2 = r[2] - sdot(Fq2, a0);
       qdd[0] = Hi[0] * t0 + Hi[1] * t1 + Hi[2] * t2; qdd[1] = Hi[1] * t0 + Hi[3] * t1 + Hi[4] * t2; qdd[2] = Hi[2] * t0 + Hi[4] * t1 + Hi[5] * t2;
-      v0f = fma6(dt, a0, v0);
+      v0f = fma6(dt, a0, F.u);
+      // T = Jb^T - K Jq^T  (hub wrench produced by a unit contact impulse), Jb_r = [x x C_r ; C_r]
+      float4 g14 = St.get(14), g15 = St.get(15), g16 = St.get(16);
+      V3 x = v3(g14.x, g14.y, g14.z), C0 = v3(g14.w, g15.x, g15.y), C1 = v3(g15.z, g15.w, g16.x), C2 = v3(g16.y, g16.z, g16.w);
+      T[0] = sv(cross(x, C0), C0); T[1] = sv(cross(x, C1), C1); T[2] = sv(cross(x, C2), C2);
     } else {
       qdd[0] = Hi[0] * r[0] + Hi[1] * r[1] + Hi[2] * r[2]; qdd[1] = Hi[1] * r[0] + Hi[3] * r[1] + Hi[4] * r[2]; qdd[2] = Hi[2] * r[0] + Hi[4] * r[1] + Hi[5] * r[2];
-      v0f = up_free;
+      float4 g17 = St.get(17), g18 = St.get(18);
+      v0f = sv(v3(g17.x, g17.y, g17.z), v3(g17.w, g18.x, g18.y));
+      unstash_sv3(St, 12, T[0], T[1], T[2]);
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -375,7 +416,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
 #pragma unroll
     for (int a = 0; a < 3; a++) qdf[a] = fmaf(dt, qdd[a], qd[a]);
     // contact operator
-    SV T[3], B[3]; float Wl[6], vf[3];
+    SV B[3]; float Wl[6], vf[3];
     float JH[3][3];   // Jq * Hinv
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
@@ -391,13 +432,12 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     Wl[5] = JH[2][0] * Jq[2][0] + JH[2][1] * Jq[2][1] + JH[2][2] * Jq[2][2];
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
+      float vq = Jq[rr][0] * qdf[0] + Jq[rr][1] * qdf[1] + Jq[rr][2] * qdf[2];
       if (MODE == 0) {
-        // T = Jb^T - K Jq^T  (hub wrench produced by a unit contact impulse)
-        T[rr] = Jb[rr] - fma6(Jq[rr][0], K0, fma6(Jq[rr][1], K1, Jq[rr][2] * K2));
-        vf[rr] = sdot(Jb[rr], v0f) + Jq[rr][0] * qdf[0] + Jq[rr][1] * qdf[1] + Jq[rr][2] * qdf[2];
+        vf[rr] = sdot(T[rr], v0f) + vq;                                   // hub row Jb_r (before the -K Jq^T part is folded in)
+        T[rr] = T[rr] - fma6(Jq[rr][0], K0, fma6(Jq[rr][1], K1, Jq[rr][2] * K2));
       } else {
-        T[rr] = Tp[rr];
-        vf[rr] = sdot(Tp[rr], v0f) + Jq[rr][0] * qdf[0] + Jq[rr][1] * qdf[1] + Jq[rr][2] * qdf[2];
+        vf[rr] = sdot(T[rr], v0f) + vq;
       }
       B[rr] = mul66(Phi, T[rr]);
     }
@@ -418,14 +458,13 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       }
       any = quad_sum_i(any);
       if (!__any(any)) break;                  // wave-uniform: nobody saturated
-      if (any == 0) { sat[0] = sat[1] = sat[2] = false; }
       // envs without saturation redo the identical unsaturated solve in pass 1 (same result)
     }
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) { qd[a] = qdn[a]; q[a] = fmaf(dt, qdn[a], q[a]); }
   F.u = un;
-  if (MODE == 0) integrate_free(F, Rb, dt); else integrate_free(F, Rf, dt);
+  integrate_free(F, Rf, dt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,7 +639,7 @@ struct StepArgs {
 };
 
 template <int MODE>
-LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const float* sTab, float* sObs, float* sSt) {
+LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const float* sTab, float* sObs, float* sSt, float4* sStash) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
   const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
   const bool active = envr < N; const int env = active ? envr : (N - 1);
@@ -608,11 +647,10 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   float* st = A.state; int64_t* cnt = A.cnt;
   const int fb = (MODE == 0) ? R_FB0 : R_FB1;
-  // ---- load
-  TaskState S; int episode;
-  S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
-  S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; episode = (int)cnt[5 * (size_t)N + env];
-  FreeBody F; V3 lin, ang; float q[3], qd[3], lqd[3], act[3];
+  Stash St; St.base = sStash; St.lane = lane;
+  // ---- load the physical state (the task-layer state is loaded after the physics to keep registers free)
+  const bool do_reset = (cnt[3 * (size_t)N + env] != 0) && !A.skip_reset;
+  FreeBody F; V3 lin, ang; float q[3], qd[3], act[3];
   F.p = v3(st[(size_t)(fb + 0) * N + env], st[(size_t)(fb + 1) * N + env], st[(size_t)(fb + 2) * N + env]);
   F.q.w = st[(size_t)(fb + 3) * N + env]; F.q.x = st[(size_t)(fb + 4) * N + env]; F.q.y = st[(size_t)(fb + 5) * N + env]; F.q.z = st[(size_t)(fb + 6) * N + env];
   lin = v3(st[(size_t)(fb + 7) * N + env], st[(size_t)(fb + 8) * N + env], st[(size_t)(fb + 9) * N + env]);
@@ -620,25 +658,15 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     q[a] = st[(size_t)(R_Q + jj[a]) * N + env]; qd[a] = st[(size_t)(R_QD + jj[a]) * N + env];
-    S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env]; lqd[a] = st[(size_t)(R_LQD + jj[a]) * N + env];
     act[a] = clampf(A.actions[(size_t)env * 12 + jj[a]], P->clip_actions);
   }
-  S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
-  S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
-  // ---- reset_idx (quadruped_pose_control.py:230-299) for flagged envs
-  if (S.reset != 0 && !A.skip_reset) {
-    float u3[3];
-    if (A.goal_rand) { u3[0] = A.goal_rand[(size_t)env * 3]; u3[1] = A.goal_rand[(size_t)env * 3 + 1]; u3[2] = A.goal_rand[(size_t)env * 3 + 2]; }
-    else hash_uniform3(A.seed, (uint32_t)env, (uint32_t)episode, u3);
-    S.goal = quat_from_euler(P->goal_lo[0] + (P->goal_hi[0] - P->goal_lo[0]) * u3[0], P->goal_lo[1] + (P->goal_hi[1] - P->goal_lo[1]) * u3[1],
-                             P->goal_lo[2] + (P->goal_hi[2] - P->goal_lo[2]) * u3[2]);
+  // ---- reset_idx (quadruped_pose_control.py:230-299), physical part
+  if (do_reset) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) { q[a] = P->init_q[jj[a]]; qd[a] = 0.f; S.lact[a] = 0.f; lqd[a] = 0.f; }
-    S.ltip = v3(P->default_tip[3 * limb], P->default_tip[3 * limb + 1], P->default_tip[3 * limb + 2]);
+    for (int a = 0; a < 3; a++) { q[a] = P->init_q[jj[a]]; qd[a] = 0.f; }
     const float* ip = (MODE == 0) ? P->init_base_pos : P->init_plate_pos; const float* iq = (MODE == 0) ? P->init_base_quat : P->init_plate_quat;
     F.p = v3(ip[0], ip[1], ip[2]); F.q.w = iq[0]; F.q.x = iq[1]; F.q.y = iq[2]; F.q.z = iq[3];
     lin = v3(0, 0, 0); ang = v3(0, 0, 0);
-    S.succ = 0; S.consec = 0; S.greset = 0; S.reset = 0; S.progress = 0; episode += 1;
   }
   // world -> body-coordinate twist
   {
@@ -648,10 +676,30 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   // ---- take_action (robot.py:452-454): velocity targets
-  float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
-  // ---- physics
-  const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
-  for (int s = 0; s < nsub; s++) substep<MODE>(P, sTab, tl, limb, F, Rfix, pfix, q, qd, tgt);
+  {
+    float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
+    const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
+    for (int s = 0; s < nsub; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt);
+  }
+  // ---- task-layer state
+  TaskState S; int episode; float lqd[3];
+  S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
+  S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; episode = (int)cnt[5 * (size_t)N + env];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env]; lqd[a] = st[(size_t)(R_LQD + jj[a]) * N + env]; }
+  S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
+  S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
+  if (do_reset) {
+    float u3[3];
+    if (A.goal_rand) { u3[0] = A.goal_rand[(size_t)env * 3]; u3[1] = A.goal_rand[(size_t)env * 3 + 1]; u3[2] = A.goal_rand[(size_t)env * 3 + 2]; }
+    else hash_uniform3(A.seed, (uint32_t)env, (uint32_t)episode, u3);
+    S.goal = quat_from_euler(P->goal_lo[0] + (P->goal_hi[0] - P->goal_lo[0]) * u3[0], P->goal_lo[1] + (P->goal_hi[1] - P->goal_lo[1]) * u3[1],
+                             P->goal_lo[2] + (P->goal_hi[2] - P->goal_lo[2]) * u3[2]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { S.lact[a] = 0.f; lqd[a] = 0.f; }
+    S.ltip = v3(P->default_tip[3 * limb], P->default_tip[3 * limb + 1], P->default_tip[3 * limb + 2]);
+    S.succ = 0; S.consec = 0; S.greset = 0; S.reset = 0; S.progress = 0; episode += 1;
+  }
   // ---- read-back (robot.py:276-321)
   TaskIn I;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
@@ -690,10 +738,11 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * 64];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
+  __shared__ float4 sStash[STASH_SLOTS * 64];
   load_table(A.table, sTab, threadIdx.x);
   const int env0 = blockIdx.x * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
-  if (P->mode == LM_MODE_LOCO) step_body<0>(A, P, sTab, sObs, sSt); else step_body<1>(A, P, sTab, sObs, sSt);
+  if (P->mode == LM_MODE_LOCO) step_body<0>(A, P, sTab, sObs, sSt, sStash); else step_body<1>(A, P, sTab, sObs, sSt, sStash);
 }
 
 // means of the reward terms + success-rate window (quadruped_pose_control.py:560,610,618-633).
@@ -787,8 +836,9 @@ LM_DEV void store_phys(float* st, int N, int env, int limb, const FreeBody& F, c
 }
 
 template <int MODE>
-LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sTab, const float* targets, int n) {
+LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sTab, const float* targets, int n, float4* sStash) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
+  Stash St; St.base = sStash; St.lane = lane;
   const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
   const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   FreeBody F; float q[3], qd[3], tgt[3];
@@ -796,14 +846,15 @@ LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sT
   for (int a = 0; a < 3; a++) tgt[a] = targets[(size_t)env * 12 + jj[a]];
   M3 Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
-  for (int s = 0; s < n; s++) substep<MODE>(P, sTab, tl, limb, F, Rfix, pfix, q, qd, tgt);
+  for (int s = 0; s < n; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt);
   if (active) store_phys<MODE>(A.state, N, env, limb, F, q, qd);
 }
 __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* targets, int n) {
   __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ float4 sStash[STASH_SLOTS * 64];
   load_table(A.table, sTab, threadIdx.x);
   const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
-  if (P->mode == LM_MODE_LOCO) substeps_body<0>(A, P, sTab, targets, n); else substeps_body<1>(A, P, sTab, targets, n);
+  if (P->mode == LM_MODE_LOCO) substeps_body<0>(A, P, sTab, targets, n, sStash); else substeps_body<1>(A, P, sTab, targets, n, sStash);
 }
 
 __global__ void __launch_bounds__(64) k_fk(StepArgs A, float* tips, float* knees) {

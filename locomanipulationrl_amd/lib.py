@@ -90,7 +90,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", _SO]
+    # -fno-slp-vectorize: packed fp32 pairs cost more v_mov / AGPR shuffles than they save here (measured: 56.0 -> 58.2 M env-steps/s)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", src, "-o", _SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
