@@ -1,0 +1,28 @@
+/*
+ * lm_policy.h -- C ABI of the GNN policy forward pass (part of liblm_engine.so).
+ *
+ * Replaces, for inference, the torch modules of RobotLearning/omniisaacgymenvs/scripts/graph_model_orebot_ov.py
+ * (GraphNet :82-110, GraphLayer :11-80, Action_Layer :215-226, Value_Layer :228-241) as instantiated by
+ * scripts/skrl_ppo_locomanipulation_vertical.py:44-49 (hidden_features = out_features = 32).
+ */
+#ifndef LM_POLICY_H
+#define LM_POLICY_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of floats in the packed parameter block:
+ *   input_layer1.weight (32,16) .bias (32) | input_layer2.weight (32,4) .bias (32) |
+ *   3 x { linear1.weight (32,64) .bias (32) | linear2.weight (32,32) .bias (32) } |
+ *   action_layer.weight (32) .bias (1) | value action_layer.weight (32) .bias (1)          (all row-major, torch layout) */
+int lm_gnn_param_count(void);
+
+/* obs: device float [batch][64] (the env's observation layout, quadruped_pose_control.py:358-371);
+ * params: device float [lm_gnn_param_count()]; mean: device float [batch][12] (node order = dof1 a1..a4, dof2 a1..a4,
+ * dof3 a1..a4); value: device float [batch].  Returns 0, -1 (bad argument) or -2 (launch failure). */
+int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+// lm_policy.hip -- GNN policy forward on the matrix cores (gfx950).
+//
+// Restates RobotLearning/omniisaacgymenvs/scripts/graph_model_orebot_ov.py:11-241 (GraphNet hidden 32, 13 nodes,
+// 24 directed edges, 3 message-passing layers with max aggregation, Action_Layer / Value_Layer heads) as one kernel:
+//   obs (B,64)  ->  action means (B,12) in node order [dof1 a1..a4, dof2 a1..a4, dof3 a1..a4], value (B,1).
+//
+// Mapping: one wavefront = 16 samples.  Every dense product runs as  D(features x samples) = W(features x K) * X(K x samples)
+// on v_mfma_f32_16x16x4_f32 (exact fp32, = an fmaf chain), weights as the A operand, activations as the B operand, so an
+// accumulator tile (feature rows in the 4 registers / 4 lane groups, sample on the lane) feeds the next product's B operand
+// with no lane movement: only the k order inside the dot product is permuted, and the A operand is gathered in the same
+// permuted order.  W1 [h_i || h_j] is split into per-node products P = W1a h + b1 (as target) and Q = W1b h (as source),
+// staged once per layer in LDS, so the 24 edge messages need only the 32x32 second linear layer:
+//   m_e = ELU(W2 ELU(P[tgt] + Q[src]) + b2),  h'[tgt] = max_e m_e.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/lm_policy.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define GNN_NODES 13
+#define GNN_EDGES 24
+#define GNN_H 32
+#define GNN_SAMPLES 16
+
+// parameter block offsets (floats)
+#define OFF_IN1_W 0                      // (32,16)
+#define OFF_IN1_B 512
+#define OFF_IN2_W 544                    // (32,4)
+#define OFF_IN2_B 672
+#define OFF_LAYER0 704
+#define LAYER_STRIDE 3136                // W1 (32,64) 2048, b1 32, W2 (32,32) 1024, b2 32
+#define OFF_ACT_W (704 + 3 * 3136)       // 32
+#define OFF_ACT_B (OFF_ACT_W + 32)
+#define OFF_VAL_W (OFF_ACT_B + 1)
+#define OFF_VAL_B (OFF_VAL_W + 32)
+
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
+
+// edges (source -> target): 0->{1..4}, i->i+4 (1..4), i->i+4 (5..8), then the 12 reverses (graph_model_orebot_ov.py:142-159)
+__device__ __forceinline__ constexpr int edge_src(int e) { return e < 4 ? 0 : (e < 8 ? e - 3 : (e < 12 ? e - 3 : (e < 16 ? e - 11 : (e < 20 ? e - 11 : e - 11)))); }
+__device__ __forceinline__ constexpr int edge_tgt(int e) { return e < 4 ? e + 1 : (e < 8 ? e + 1 : (e < 12 ? e + 1 : (e < 16 ? 0 : (e < 20 ? e - 15 : e - 15)))); }
+// obs column of feature k (0..3) of joint node n (1..12): [0.3 q, 0.3 qd, action, last action] of that joint (:115-126)
+__device__ __forceinline__ constexpr int joint_col(int n, int k) { return 16 + 12 * k + (n <= 4 ? n - 1 : (n <= 8 ? 4 + 2 * (n - 5) : 5 + 2 * (n - 9))); }
+
+__global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
+                                                    float* __restrict__ mean, float* __restrict__ value) {
+  __shared__ float sPQ[GNN_NODES * 64 * GNN_SAMPLES];          // [node][feature 0..63][sample]
+  const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+  const int s0 = blockIdx.x * GNN_SAMPLES;
+  const int sample = min(s0 + n, B - 1);
+  const float* ob = obs + (size_t)sample * 64;
+
+  f32x4 h[GNN_NODES][2];            // node features, C layout: h[node][mb][i] = feature 16 mb + 4 g + i of sample n
+  // ---- input layers (:97-104)
+  {
+    // node 0: Linear(16,32) on obs[0:16]
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        float a = W[OFF_IN1_W + (16 * mb + n) * 16 + 4 * s + g];
+        float b = ob[4 * s + g];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] += W[OFF_IN1_B + 16 * mb + 4 * g + i];
+      h[0][mb] = acc;
+    }
+    // joint nodes: shared Linear(4,32)
+    float a2[2] = {W[OFF_IN2_W + (n) * 4 + g], W[OFF_IN2_W + (16 + n) * 4 + g]};
+#pragma unroll
+    for (int nd = 1; nd < GNN_NODES; nd++) {
+      float b = (g == 0) ? ob[joint_col(nd, 0)] : (g == 1) ? ob[joint_col(nd, 1)] : (g == 2) ? ob[joint_col(nd, 2)] : ob[joint_col(nd, 3)];
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb], b, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] += W[OFF_IN2_B + 16 * mb + 4 * g + i];
+        h[nd][mb] = acc;
+      }
+    }
+  }
+  // ---- three message-passing layers
+  for (int layer = 0; layer < 3; layer++) {
+    const float* L = W + OFF_LAYER0 + layer * LAYER_STRIDE;
+    const float* W1 = L; const float* b1 = L + 2048; const float* W2 = L + 2080; const float* b2 = L + 3104;
+    // stage 1: P = W1[:, 0:32] h + b1, Q = W1[:, 32:64] h  for every node -> LDS.
+    // output feature block ob4 (0,1 = P rows 0..31; 2,3 = Q rows 0..31); k-step (mb', i) reads h[node][mb'][i] = feature 16 mb' + 4 g + i
+    float wa[4][8];
+#pragma unroll
+    for (int ob4 = 0; ob4 < 4; ob4++)
+#pragma unroll
+      for (int st = 0; st < 8; st++) {
+        int row = 16 * (ob4 & 1) + n, col = 32 * (ob4 >> 1) + 16 * (st >> 2) + 4 * g + (st & 3);
+        wa[ob4][st] = W1[row * 64 + col];
+      }
+    float bias1[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) bias1[mb][i] = b1[16 * mb + 4 * g + i];
+#pragma unroll
+    for (int nd = 0; nd < GNN_NODES; nd++) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 8; st++) {
+        float b = h[nd][st >> 2][st & 3];
+#pragma unroll
+        for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ob4][st], b, acc[ob4], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ob4 = 0; ob4 < 4; ob4++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float v = acc[ob4][i] + ((ob4 < 2) ? bias1[ob4][i] : 0.f);
+          sPQ[(nd * 64 + 16 * ob4 + 4 * g + i) * GNN_SAMPLES + n] = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // stage 2: messages along the 24 edges, max-aggregated on the target node
+    float wb[2][8];
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+      for (int st = 0; st < 8; st++) wb[mb][st] = W2[(16 * mb + n) * 32 + 4 * st + g];
+    float bias2[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
+#pragma unroll
+    for (int nd = 0; nd < GNN_NODES; nd++)
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) h[nd][mb] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int e = 0; e < GNN_EDGES; e++) {
+      const int src = edge_src(e), tgt = edge_tgt(e);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 8; st++) {
+        int k = 4 * st + g;
+        float z = elu(sPQ[(tgt * 64 + k) * GNN_SAMPLES + n] + sPQ[(src * 64 + 32 + k) * GNN_SAMPLES + n]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], z, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        h[tgt][0][i] = fmaxf(h[tgt][0][i], elu(acc0[i] + bias2[0][i]));
+        h[tgt][1][i] = fmaxf(h[tgt][1][i], elu(acc1[i] + bias2[1][i]));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();       // all lanes done reading sPQ before the next layer overwrites it
+  }
+  // ---- heads (:215-241): action mean of joint node j = Linear(32,1)(h[1+j]); value = Linear(32,1)(max over nodes)
+  float wact[2][4], wval[2][4];
+#pragma unroll
+  for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { wact[mb][i] = W[OFF_ACT_W + 16 * mb + 4 * g + i]; wval[mb][i] = W[OFF_VAL_W + 16 * mb + 4 * g + i]; }
+  const bool write = (g == 0) && (s0 + n < B);
+  f32x4 hm0 = h[0][0], hm1 = h[0][1];
+#pragma unroll
+  for (int nd = 1; nd < GNN_NODES; nd++) {
+    float p = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      p = fmaf(wact[0][i], h[nd][0][i], p); p = fmaf(wact[1][i], h[nd][1][i], p);
+      hm0[i] = fmaxf(hm0[i], h[nd][0][i]); hm1[i] = fmaxf(hm1[i], h[nd][1][i]);
+    }
+    p += __shfl_xor(p, 16); p += __shfl_xor(p, 32);
+    if (write) mean[(size_t)(s0 + n) * 12 + (nd - 1)] = p + W[OFF_ACT_B];
+  }
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v = fmaf(wval[0][i], hm0[i], v); v = fmaf(wval[1][i], hm1[i], v); }
+  v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+  if (write) value[s0 + n] = v + W[OFF_VAL_B];
+}
+
+extern "C" {
+
+int lm_gnn_param_count(void) { return OFF_VAL_B + 1; }
+
+int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
+  if (!obs || !params || !mean || !value || batch <= 0) return -1;
+  int blocks = (batch + GNN_SAMPLES - 1) / GNN_SAMPLES;
+  hipLaunchKernelGGL(k_gnn_forward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, obs, batch, params, mean, value);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

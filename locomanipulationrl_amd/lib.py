@@ -21,7 +21,8 @@ PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_ST
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
-           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_set_seed", "lm_last_error", "lm_version"]
+           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_set_seed", "lm_last_error", "lm_version",
+           "lm_gnn_param_count", "lm_gnn_forward"]
 
 # rows of the SoA float state
 ROW = dict(base_pos=0, base_quat=3, base_lin=7, base_ang=10, q=13, qd=25, plate_pos=37, plate_quat=40, plate_lin=44,
@@ -85,13 +86,14 @@ def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParam
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/lm_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_CSRC, "lm_engine.hip")
-    deps = [src, os.path.join(_CSRC, "lm_math.h"),
-            os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "lm_engine.h")]
+    src2 = os.path.join(_CSRC, "lm_policy.hip")
+    inc = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include")
+    deps = [src, src2, os.path.join(_CSRC, "lm_math.h"), os.path.join(inc, "lm_engine.h"), os.path.join(inc, "lm_policy.h")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
     # -fno-slp-vectorize: packed fp32 pairs cost more v_mov / AGPR shuffles than they save here (measured: 56.0 -> 58.2 M env-steps/s)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", src, "-o", _SO]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", src, src2, "-o", _SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -124,6 +126,7 @@ def load_library() -> C.CDLL:
     lib.lm_ptr.argtypes = [vp, ip]; lib.lm_ptr.restype = vp
     lib.lm_num_envs.argtypes = [vp]
     lib.lm_set_seed.argtypes = [vp, C.c_uint32]
+    lib.lm_gnn_forward.argtypes = [fp, ip, fp, fp, fp, vp]
     lib.lm_last_error.restype = C.c_char_p
     lib.lm_version.restype = C.c_char_p
     _lib = lib

@@ -12,7 +12,7 @@ import pytest
 from conftest import ROOT
 from locomanipulationrl_amd import lib as lmlib
 
-HEADER = os.path.join(ROOT, "include", "lm_engine.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("lm_engine.h", "lm_policy.h")]
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +22,7 @@ def so():
 
 
 def declared_symbols():
-    text = open(HEADER).read()
+    text = "".join(open(h).read() for h in HEADERS)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(lm_[a-z_0-9]+)\s*\(", text)))
 

@@ -1,0 +1,94 @@
+"""GNN policy: numpy oracle and torch modules pinned to the reference's own GraphNet outputs
+(tests/golden/gnn.npz); the matrix-core HIP forward against both on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from locomanipulationrl_amd.policies.graph_model import (Action_Layer, GraphNet, GraphPolicy, Value_Layer, create_edge_index,
+                                                         pack_gnn_params)
+from oracle.gnn_ref import gnn_forward
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "gnn.npz"))
+
+
+def state_dict(g):
+    return {k: g[k] for k in g.files if k.startswith(("net.", "mean_layer.", "value_layer."))}
+
+
+def load_modules(g):
+    net, act, val = GraphNet(32, 32), Action_Layer(32, 12), Value_Layer(32)
+    net.load_state_dict({k[4:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("net.")})
+    act.load_state_dict({k[len("mean_layer."):]: torch.as_tensor(g[k]) for k in g.files if k.startswith("mean_layer.")})
+    val.load_state_dict({k[len("value_layer."):]: torch.as_tensor(g[k]) for k in g.files if k.startswith("value_layer.")})
+    return net, act, val
+
+
+def test_numpy_oracle_matches_reference(golden):
+    h, mean, value = gnn_forward(golden["obs"], state_dict(golden))
+    assert np.abs(h - golden["h"]).max() < 2e-6 and np.abs(mean - golden["mean"]).max() < 2e-6 and np.abs(value - golden["value"]).max() < 2e-6
+    assert np.array_equal(create_edge_index().numpy(), golden["edge_index"])
+
+
+def test_torch_modules_are_state_dict_compatible_with_reference(golden):
+    net, act, val = load_modules(golden)
+    with torch.no_grad():
+        h = net(torch.as_tensor(golden["obs"]))
+        assert (h - torch.as_tensor(golden["h"])).abs().max() < 1e-6
+        assert (act(h) - torch.as_tensor(golden["mean"])).abs().max() < 1e-6
+        assert (val(h) - torch.as_tensor(golden["value"])).abs().max() < 1e-6
+    # trainable: gradients flow to every parameter
+    pol = GraphPolicy()
+    mean, log_std, value = pol(torch.randn(8, 64))
+    (mean.sum() + value.sum()).backward()
+    assert all(p.grad is not None for n, p in pol.named_parameters() if n != "log_std_parameter")
+    assert mean.shape == (8, 12) and value.shape == (8, 1) and log_std.shape == (12,)
+
+
+def test_param_packing_size(golden):
+    net, act, val = load_modules(golden)
+    assert pack_gnn_params(net, act, val).numel() == 704 + 3 * 3136 + 66
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [40, 8192, 8197])          # golden batch, BASELINE config 5 size, ragged last wavefront
+def test_hip_forward_matches_reference_and_oracle(golden, B):
+    from locomanipulationrl_amd.lib import build_library
+    from locomanipulationrl_amd.policies.graph_model import gnn_forward_hip
+    build_library()
+    net, act, val = load_modules(golden)
+    packed = pack_gnn_params(net, act, val).cuda()
+    if B == 40:
+        obs = torch.as_tensor(golden["obs"]).cuda()
+        ref_mean, ref_value = golden["mean"], golden["value"]
+    else:
+        obs = (torch.randn(B, 64, generator=torch.Generator().manual_seed(B)) * 1.5).cuda()
+        _, ref_mean, ref_value = gnn_forward(obs.cpu().numpy(), state_dict(golden))
+    mean, value = gnn_forward_hip(obs.contiguous(), packed)
+    torch.cuda.synchronize()
+    # fp32 MFMA = an fmaf chain (exact fp32 products): tolerance 1e-5 on O(1) outputs
+    assert np.abs(mean.cpu().numpy() - ref_mean).max() < 1e-5
+    assert np.abs(value.cpu().numpy() - ref_value).max() < 1e-5
+    with torch.no_grad():
+        h = net.cuda()(obs)
+        assert (act.cuda()(h) - mean).abs().max() < 1e-5 and (val.cuda()(h) - value).abs().max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gnn_policy_drives_vertical_env():
+    """BASELINE config 5: vertical configuration + GNN policy in the loop (actions from the policy, not zeroed)."""
+    import locomanipulationrl_amd as lm
+    env = lm.make_env("QuadrupedPoseControlVertical", num_envs=512)
+    pol = GraphPolicy().cuda()
+    obs = env.reset()["obs"]
+    for _ in range(20):
+        mean, log_std, value = pol.act_inference(obs.contiguous())
+        o, rew, resets, _ = env.step(mean.clamp(-1, 1))
+        obs = o["obs"]
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(mean).all()
+    env.close()

@@ -352,6 +352,38 @@ def gen_take_action(seed=5, N=8):
     return out
 
 
+def gen_gnn(seed=11, B=40):
+    """The reference's GraphNet / Action_Layer / Value_Layer (scripts/graph_model_orebot_ov.py) on random inputs with seeded
+    weights.  torch_scatter (third-party, absent) is replaced by a stand-in with its documented semantics:
+    scatter(src, index, dim, dim_size, reduce='max') = per-index maximum, 0 where an index receives nothing."""
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter(src, index, dim=-1, dim_size=None, reduce="sum"):
+        assert reduce == "max" and dim == -2
+        out = torch.zeros(src.shape[:-2] + (dim_size, src.shape[-1]), dtype=src.dtype)
+        idx = index.view(1, -1, 1).expand(src.shape)
+        return out.scatter_reduce(-2, idx, src, reduce="amax", include_self=False)
+
+    ts.scatter = scatter
+    sys.modules["torch_scatter"] = ts
+    sys.path.insert(0, os.path.join(REF_RL, "scripts"))
+    import graph_model_orebot_ov as G
+    torch.manual_seed(seed)
+    net = G.GraphNet(hidden_features=32, out_features=32); act = G.Action_Layer(32, 12); val = G.Value_Layer(32)
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(B, 64, generator=g) * 1.5
+    with torch.no_grad():
+        h = net(obs); mean = act(h); value = val(h)
+    out = {"obs": obs, "h": h, "mean": mean, "value": value, "edge_index": net.edge_index}
+    for k, v in net.state_dict().items():
+        out["net." + k] = v
+    for k, v in act.state_dict().items():
+        out["mean_layer." + k] = v
+    for k, v in val.state_dict().items():
+        out["value_layer." + k] = v
+    return {k: v.numpy() for k, v in out.items()}
+
+
 def main():
     assert os.path.isdir(REF_RL), "reference tree not present: golden vectors can only be regenerated in the build container"
     _install_placeholders()
@@ -365,6 +397,7 @@ def main():
               "bonus steps", int((d["rew"] > 300).sum()))
     np.savez_compressed(os.path.join(OUT, "math.npz"), **gen_math())
     np.savez_compressed(os.path.join(OUT, "take_action.npz"), **gen_take_action())
+    np.savez_compressed(os.path.join(OUT, "gnn.npz"), **gen_gnn())
     print("wrote", sorted(os.listdir(OUT)))
 
 
