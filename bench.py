@@ -27,7 +27,7 @@ ROLLOUT = 48
 BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (460 read + 1028 written)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
-FLOP_PER_ENV_STEP = 0.52e6         # counted from the kernel ISA: VALU flops per env-step
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v2.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
 
 
 def cpu_baseline(steps: int = 150, envs: int = 4096):
@@ -121,6 +121,9 @@ def main():
         k_ms = sorted(a.elapsed_time(b) for a, b in evs)
         k_avg_ms = sum(k_ms) / len(k_ms)
         achieved = BYTES_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e9
+        pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
+        traffic = pmc["per_launch"]["hbm_traffic_bytes"] if pmc else None
+        flop_env = pmc["flop_per_env_step"] if pmc else 1.67e5
         value = world * N * args.steps / elapsed
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
@@ -130,10 +133,11 @@ def main():
                                    "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_step(+k_finalize)", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
+                         "traffic": traffic, "kernel": "k_step(+k_finalize)", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
-            "valu": {"achieved": FLOP_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": FLOP_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64},
+            "valu": {"achieved": flop_env * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flop_env * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64,
+                     "flop_per_env_step": flop_env},
         }
     eng.close()
     if world > 1:
