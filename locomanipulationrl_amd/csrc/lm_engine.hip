@@ -618,7 +618,7 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   }
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) W.partials[(size_t)blockIdx.x * NPART + k] = part[k];
+    for (int k = 0; k < 9; k++) W.partials[(size_t)k * gridDim.x + blockIdx.x] = part[k];      // [k][block]: coalesced for k_finalize
   }
 }
 
@@ -746,24 +746,32 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
 }
 
 // means of the reward terms + success-rate window (quadruped_pose_control.py:560,610,618-633).
-// 256 threads: thread (c, k) sums every 16th block's partial k in a fixed order, then a fixed-order LDS tree
-// -> deterministic, and no serial 256-long dependent-load chain.
+// 256 threads: coalesced loads of the [k][block] partials (all independent, one round trip), fixed-order shuffle + LDS tree
+// -> deterministic sums without a serial dependent-load chain.
 __global__ void __launch_bounds__(256) k_finalize(const float* partials, int nblocks, int N, const lm_params* P, char* stats, float* extras, float* out_extras) {
-  __shared__ float red[16][16];
-  const int k = threadIdx.x & 15, c = threadIdx.x >> 4;
-  float s = 0.f;
-  if (k < 9) for (int b = c; b < nblocks; b += 16) s += partials[(size_t)b * NPART + k];
-  red[c][k] = s;
-  __syncthreads();
-  if (threadIdx.x < 9) {
-    float t = 0.f;
+  __shared__ float red[4][12];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  float s[9];
 #pragma unroll
-    for (int i = 0; i < 16; i++) t += red[i][threadIdx.x];
-    red[0][threadIdx.x] = t;
-    if (threadIdx.x < 7) { float m = t / (float)N; extras[threadIdx.x] = m; if (out_extras) out_extras[threadIdx.x] = m; }
+  for (int k = 0; k < 9; k++) {
+    float a = 0.f;
+    for (int b = t; b < nblocks; b += 256) a += partials[(size_t)k * nblocks + b];
+    s[k] = a;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    float a = s[k];
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+    if (lane == 0) red[wv][k] = a;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (t < 9) {
+    float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    red[0][t] = tot;
+    if (t < 7) { float m = tot / (float)N; extras[t] = m; if (out_extras) out_extras[t] = m; }
+  }
+  __syncthreads();
+  if (t == 0) {
     int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 16);
     int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
     if (num_rst > (int64_t)P->max_reset_counts) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
