@@ -36,7 +36,7 @@ extern "C" {
 #define LM_NUM_OBS 64
 #define LM_NUM_STATES 93
 #define LM_NUM_ACTIONS 12
-#define LM_NUM_EXTRAS 8
+#define LM_NUM_EXTRAS 10  /* 7 reward-term means, success_rate, success_rate of task 0 / task 1 (co-train) */
 #define LM_TABLE_FLOATS 486  /* 10 hub + 4 x 119 limb (RobotModel.packed_table) */
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
@@ -71,8 +71,8 @@ typedef enum {
   LM_PTR_OBS_BUF = 2,   /* float [N][64]  task.obs_buf (unclipped)   rl_task.py:107  */
   LM_PTR_STATES_BUF = 3,/* float [N][93]  task.states_buf                            */
   LM_PTR_REW_BUF = 4,   /* float [N]      task.rew_buf                               */
-  LM_PTR_EXTRAS = 5,    /* float [8]      reward-term means + success_rate           */
-  LM_PTR_STATS = 6,     /* int64 [2] num_successes, num_resets ; then float success_rate at byte 16 */
+  LM_PTR_EXTRAS = 5,    /* float [10]     reward-term means + success rates           */
+  LM_PTR_STATS = 6,     /* int64 [6] {num_successes, num_resets} x {all, task 0, task 1}; float [3] rates at byte 48 */
   LM_PTR_TERMS = 7      /* float [8][N]   per-env reward terms of the last step      */
 } lm_ptr_kind;
 
@@ -92,7 +92,7 @@ int lm_destroy(lm_engine* h);
  *   actions     device float [N][12]
  *   goal_rand   device float [N][3] uniforms for goal sampling, or NULL for the in-kernel hash RNG
  *   out_*       device buffers receiving clipped copies for the caller (any may be NULL):
- *               obs [N][64], states [N][93], rew [N], resets int64 [N], extras float [8]
+ *               obs [N][64], states [N][93], rew [N], resets int64 [N], extras float [LM_NUM_EXTRAS]
  *   stream      hipStream_t (void* here so the header needs no HIP include) */
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states,
             float* out_rew, int64_t* out_resets, float* out_extras, void* stream);

@@ -46,7 +46,7 @@ struct lm_engine {
   float* d_table;
   float* d_state; int64_t* d_cnt;
   float *d_obs, *d_states, *d_rew, *d_extras, *d_terms, *d_partials;
-  char* d_stats;           // int64 num_successes, int64 num_resets, float success_rate
+  char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48
   lm_params h_params[2];
 };
 
@@ -745,39 +745,51 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   if (P->mode == LM_MODE_LOCO) step_body<0>(A, P, sTab, sObs, sSt, sStash); else step_body<1>(A, P, sTab, sObs, sSt, sStash);
 }
 
-// means of the reward terms + success-rate window (quadruped_pose_control.py:560,610,618-633).
+// means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps
+// two more windows for its locomotion / manipulation halves, joint_locomanipulation.py:795-859).
 // 256 threads: coalesced loads of the [k][block] partials (all independent, one round trip), fixed-order shuffle + LDS tree
-// -> deterministic sums without a serial dependent-load chain.
-__global__ void __launch_bounds__(256) k_finalize(const float* partials, int nblocks, int N, const lm_params* P, char* stats, float* extras, float* out_extras) {
-  __shared__ float red[4][12];
+// -> deterministic sums without a serial dependent-load chain.  split_block = first block of the second task.
+LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
+  int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
+  if (num_rst > max_cnt) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
+  ns[0] = num_succ + add_succ; ns[1] = num_rst + add_rst; *rate = sr;
+}
+__global__ void __launch_bounds__(256) k_finalize(const float* partials, int nblocks, int split_block, int N, const lm_params* P, char* stats,
+                                                  float* extras, float* out_extras) {
+  __shared__ float red[4][16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  float s[9];
+  float s[11];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     float a = 0.f;
     for (int b = t; b < nblocks; b += 256) a += partials[(size_t)k * nblocks + b];
     s[k] = a;
   }
+  // first-task (locomotion half) share of the goal-reset / reset counts
+  s[9] = 0.f; s[10] = 0.f;
+  for (int b = t; b < split_block; b += 256) { s[9] += partials[(size_t)7 * nblocks + b]; s[10] += partials[(size_t)8 * nblocks + b]; }
 #pragma unroll
-  for (int k = 0; k < 9; k++) {
+  for (int k = 0; k < 11; k++) {
     float a = s[k];
     a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
     if (lane == 0) red[wv][k] = a;
   }
   __syncthreads();
-  if (t < 9) {
+  if (t < 11) {
     float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     red[0][t] = tot;
     if (t < 7) { float m = tot / (float)N; extras[t] = m; if (out_extras) out_extras[t] = m; }
   }
   __syncthreads();
   if (t == 0) {
-    int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 16);
-    int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
-    if (num_rst > (int64_t)P->max_reset_counts) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
-    num_succ += (int64_t)(red[0][7] + 0.5f); num_rst += (int64_t)(red[0][8] + 0.5f);
-    ns[0] = num_succ; ns[1] = num_rst; *rate = sr;
-    extras[7] = sr; if (out_extras) out_extras[7] = sr;
+    int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 48);
+    const int64_t gs = (int64_t)(red[0][7] + 0.5f), rs = (int64_t)(red[0][8] + 0.5f);
+    const int64_t gl = (int64_t)(red[0][9] + 0.5f), rl = (int64_t)(red[0][10] + 0.5f);
+    success_window(ns + 0, rate + 0, gs, rs, (int64_t)P->max_reset_counts);
+    success_window(ns + 2, rate + 1, gl, rl, (int64_t)P->max_reset_counts);
+    success_window(ns + 4, rate + 2, gs - gl, rs - rl, (int64_t)P->max_reset_counts);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { extras[7 + k] = rate[k]; if (out_extras) out_extras[7 + k] = rate[k]; }
   }
 }
 
@@ -1052,7 +1064,7 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets);
   hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -1064,7 +1076,7 @@ int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* o
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
   A.skip_reset = 1; A.nsub = 0;
   hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -1082,7 +1094,7 @@ int lm_task_eval(lm_engine* h, const float* readback, const float* actions, floa
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
   hipLaunchKernelGGL(k_task_eval, dim3(h->nblocks), dim3(64), 0, s, A, readback);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }

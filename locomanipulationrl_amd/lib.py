@@ -16,7 +16,7 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.path.join(_CSRC, "liblm_engine.so")
 
-STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS = 90, 6, 64, 93, 12, 8, 486
+STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS = 90, 6, 64, 93, 12, 10, 486
 PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS = range(8)
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
@@ -174,7 +174,7 @@ class Engine:
         self.rew_buf = self._wrap(PTR_REW_BUF, (N,), "<f4")
         self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
         self.terms = self._wrap(PTR_TERMS, (8, N), "<f4")
-        self.stats_i64 = self._wrap(PTR_STATS, (2,), "<i8")
+        self.stats_i64 = self._wrap(PTR_STATS, (6,), "<i8")
 
     # ------------------------------------------------------------------
     def _check(self, rc: int):

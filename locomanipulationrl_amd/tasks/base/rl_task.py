@@ -20,6 +20,7 @@ from ...utils.spaces import Box
 EXTRAS_KEYS = ["env/rewards/orientation_rew", "env/rewards/translation_penalty", "env/rewards/joint_acc_penalty",
                "env/rewards/action_rate_penalty", "env/rewards/consecutive_successes_rew", "env/rewards/joint_limit_panelty",
                "env/rewards/fall_penalty", "env/success_rate"]     # ("panelty": sic, quadruped_pose_control.py:526)
+COTRAIN_EXTRAS_KEYS = ["env/success_rate_loco", "env/success_rate_mani"]                     # joint_locomanipulation.py:857-859
 
 
 class _InertRandomizer:
@@ -141,11 +142,13 @@ class RLTask:
     def _alloc_outputs(self):
         N, dev = self._num_envs, self._device
         return (torch.empty((N, 64), device=dev), torch.empty((N, 93), device=dev), torch.empty((N,), device=dev),
-                torch.empty((N,), dtype=torch.int64, device=dev), torch.empty((8,), device=dev))
+                torch.empty((N,), dtype=torch.int64, device=dev), torch.empty((10,), device=dev))
 
     def _publish(self, out):
         obs, states, rew, resets, extras = out
         self.extras = {k: extras[i] for i, k in enumerate(EXTRAS_KEYS)}
+        if self.split_env() is not None:
+            self.extras.update({k: extras[8 + i] for i, k in enumerate(COTRAIN_EXTRAS_KEYS)})
         if self.num_states == self.num_observations:
             states = obs
         return obs, states, rew, resets, self.extras

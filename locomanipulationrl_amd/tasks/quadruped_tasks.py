@@ -196,6 +196,7 @@ class JointLocomanipulation(_QuadrupedTask):
     the goal to a single orientation and exits after recording two trajectories (:61-66,861-874); the ranges of
     the single tasks are used instead."""
     _num_states = 64
+    baseline_knee_height = -1.0e9          # the co-train is_done carries no knee test (joint_locomanipulation.py:712-770)
     default_obj_position = [0.0, 0.0, 0.68]
     mani_base_position = [0.0, 0.0, 0.5]
 

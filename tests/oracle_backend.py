@@ -20,8 +20,8 @@ class OracleEngine:
         self.state = torch.zeros((90, self.N), dtype=torch.float32)
         self.cnt = torch.zeros((6, self.N), dtype=torch.int64)
         self.obs_buf = torch.zeros((self.N, 64)); self.states_buf = torch.zeros((self.N, 93)); self.rew_buf = torch.zeros(self.N)
-        self.extras_buf = torch.zeros(8); self.terms = torch.zeros((8, self.N)); self.stats_i64 = torch.zeros(2, dtype=torch.int64)
-        self._sr = 0.0
+        self.extras_buf = torch.zeros(10); self.terms = torch.zeros((8, self.N)); self.stats_i64 = torch.zeros(6, dtype=torch.int64)
+        self._sr = [0.0, 0.0, 0.0]
         self._sync_out()
 
     def _halves(self):
@@ -41,12 +41,14 @@ class OracleEngine:
         self.obs_buf[:] = torch.as_tensor(obs.astype(np.float32)); self.states_buf[:] = torch.as_tensor(states.astype(np.float32))
         self.rew_buf[:] = torch.as_tensor(rew.astype(np.float32)); self.terms[:] = torch.as_tensor(terms.T.astype(np.float32))
         means = terms[:, :7].mean(0)
-        ns, nr = int(self.stats_i64[0]), int(self.stats_i64[1])
-        if nr > self.params[0].max_reset_counts:
-            self._sr = ns / nr; ns = nr = 0
-        ns += int(round(terms[:, 7].sum())); nr += int(self.cntv[:, 3].sum())
-        self.stats_i64[0] = ns; self.stats_i64[1] = nr
-        self.extras_buf[:7] = torch.as_tensor(means.astype(np.float32)); self.extras_buf[7] = self._sr
+        for w, sl in enumerate((slice(0, self.N), slice(0, self.split), slice(self.split, self.N))):
+            ns, nr = int(self.stats_i64[2 * w]), int(self.stats_i64[2 * w + 1])
+            if nr > self.params[0].max_reset_counts:
+                self._sr[w] = ns / nr; ns = nr = 0
+            ns += int(round(terms[sl, 7].sum())); nr += int(self.cntv[sl, 3].sum())
+            self.stats_i64[2 * w] = ns; self.stats_i64[2 * w + 1] = nr
+            self.extras_buf[7 + w] = self._sr[w]
+        self.extras_buf[:7] = torch.as_tensor(means.astype(np.float32))
         self._sync_out()
         out_obs, out_states, out_rew, out_resets, out_extras = outs
         c = self.clip_obs

@@ -95,6 +95,8 @@ def test_cotrain_layout():
     assert env.num_states == 64
     o = env.reset()
     assert o["states"].shape == (32, 64) and torch.equal(o["obs"], o["states"])          # joint_locomanipulation.py:548
+    _, _, _, extras = env.step(torch.zeros(32, 12))
+    assert {"env/success_rate", "env/success_rate_loco", "env/success_rate_mani"} <= set(extras.keys())   # :857-859
     t = env._task
     assert t.robot_locomotion.joint_positions.shape == (16, 12) and t.robot_manipulation.joint_positions.shape == (16, 12)
     # loco half: base at z~0.18 above ground; mani half: plate around z 0.68 over the inverted robot at 0.5
