@@ -700,6 +700,22 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     S.ltip = v3(P->default_tip[3 * limb], P->default_tip[3 * limb + 1], P->default_tip[3 * limb + 2]);
     S.succ = 0; S.consec = 0; S.greset = 0; S.reset = 0; S.progress = 0; episode += 1;
   }
+  // ---- blow-up guard: the reference only prints NaNs and asserts (quadruped_pose_control.py:550-558); here a non-finite or
+  // exploding state is replaced by the reset pose and the env is flagged for reset, so one bad env cannot poison a batch
+  int blown = 0;
+  {
+    float chk = F.p.x + F.p.y + F.p.z + F.q.w + F.q.x + F.q.y + F.q.z + F.u.w.x + F.u.w.y + F.u.w.z + F.u.v.x + F.u.v.y + F.u.v.z
+              + q[0] + q[1] + q[2] + qd[0] + qd[1] + qd[2];
+    float big = fmaxf(fmaxf(fabsf(qd[0]), fabsf(qd[1])), fmaxf(fabsf(qd[2]), fabsf(F.u.v.x) + fabsf(F.u.v.y) + fabsf(F.u.v.z)));
+    blown = quad_sum_i((!(fabsf(chk) < 1.0e30f) || big > 1.0e4f) ? 1 : 0);
+    if (blown) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { q[a] = P->init_q[jj[a]]; qd[a] = 0.f; }
+      const float* ip = (MODE == 0) ? P->init_base_pos : P->init_plate_pos; const float* iq = (MODE == 0) ? P->init_base_quat : P->init_plate_quat;
+      F.p = v3(ip[0], ip[1], ip[2]); F.q.w = iq[0]; F.q.x = iq[1]; F.q.y = iq[2]; F.q.z = iq[3];
+      F.u = sv(v3(0, 0, 0), v3(0, 0, 0));
+    }
+  }
   // ---- read-back (robot.py:276-321)
   TaskIn I;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
@@ -715,6 +731,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a]; }
   TaskOut O;
   task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
+  if (blown) S.reset = 1;
   // ---- store state
   if (active) {
 #pragma unroll

@@ -275,3 +275,22 @@ def test_every_task_config_two_step_parity(engine_cls, oracle_cls, task_name):
             assert np.abs(grew[sl][ok] - rw[ok]).max() < 5e-3 * max(1.0, np.abs(rw).max())
             assert np.isfinite(gobs).all()
     eng.close()
+
+
+def test_blowup_guard_forces_reset(robot_model, engine_cls):
+    """A non-finite state in one env is contained: that env is flagged for reset and restarts from the reset pose;
+    its neighbours in the same wavefront are untouched (failure detection)."""
+    N = 32; ep = loco_params()
+    e1 = engine_cls(robot_model, [ep], N, seed=1); e2 = engine_cls(robot_model, [ep], N, seed=1)
+    a = torch.zeros(N, 12, device="cuda")
+    for e in (e1, e2):
+        o = outs(N); e.step(a, None, *o)
+    e1.state[25, 5] = float("nan")          # joint velocity of env 5
+    e1.state[2, 9] = float("inf")           # base height of env 9
+    o1, o2 = outs(N), outs(N)
+    e1.step(a, None, *o1); e2.step(a, None, *o2); torch.cuda.synchronize()
+    assert torch.isfinite(o1[0]).all() and torch.isfinite(o1[2]).all() and torch.isfinite(e1.state).all()
+    assert int(o1[3][5]) == 1 and int(o1[3][9]) == 1
+    keep = [i for i in range(N) if i not in (5, 9)]
+    assert torch.equal(o1[0][keep], o2[0][keep]) and torch.equal(o1[3][keep], o2[3][keep])
+    for e in (e1, e2): e.close()
