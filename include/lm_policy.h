@@ -22,6 +22,14 @@ int lm_gnn_param_count(void);
  * dof3 a1..a4); value: device float [batch].  Returns 0, -1 (bad argument) or -2 (launch failure). */
 int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream);
 
+/* MLP policy of the locomotion / manipulation scripts (scripts/skrl_ppo_locomotion.py:30-40: shared trunk
+ * Linear(64,256) ELU Linear(256,128) ELU Linear(128,64) ELU, mean_layer Linear(64,12), value_layer Linear(64,1)) with the
+ * observation preprocessor (skrl RunningStandardScaler, :96-99) folded in.  `params` is the block produced by
+ * locomanipulationrl_amd.policies.mlp_model.pack_mlp_params (weights pre-permuted into MFMA operand order);
+ * lm_mlp_param_count() is its length.  Outputs as lm_gnn_forward (mean in the env's action order). */
+int lm_mlp_param_count(void);
+int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

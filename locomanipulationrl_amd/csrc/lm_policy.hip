@@ -183,7 +183,83 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
   if (write) value[s0 + n] = v + W[OFF_VAL_B];
 }
 
+// ------------------------------------------------------------------------------------------------
+// MLP policy (scripts/skrl_ppo_locomotion.py:30-40): shared trunk 64 -> 256 -> 128 -> 64 (ELU) -> mean (12) + value (1),
+// with the observation preprocessor folded in (skrl RunningStandardScaler: clamp((x - mean) / (sqrt(var) + eps), +-clip),
+// passed as mean / inverse-std vectors).  Same orientation as the GNN: weights are the MFMA A operand, pre-permuted on the
+// host into the per-lane order each v_mfma_f32_16x16x4_f32 consumes (one coalesced 256-byte load per MFMA), activations stay
+// in accumulator layout from layer to layer.
+//   packed block: obs_mean 64 | obs_inv_std 64 | clip 1 (+3 pad) | W1p 256x64 | b1 256 | W2p 128x256 | b2 128 | W3p 64x128 | b3 64 |
+//                 Whp 16x64 (rows 0..11 mean, 12 value, 13..15 zero) | bh 16
+#define MLP_OFF_MEAN 0
+#define MLP_OFF_ISTD 64
+#define MLP_OFF_CLIP 128
+#define MLP_OFF_W1 132
+#define MLP_OFF_B1 (MLP_OFF_W1 + 256 * 64)
+#define MLP_OFF_W2 (MLP_OFF_B1 + 256)
+#define MLP_OFF_B2 (MLP_OFF_W2 + 128 * 256)
+#define MLP_OFF_W3 (MLP_OFF_B2 + 128)
+#define MLP_OFF_B3 (MLP_OFF_W3 + 64 * 128)
+#define MLP_OFF_WH (MLP_OFF_B3 + 64)
+#define MLP_OFF_BH (MLP_OFF_WH + 16 * 64)
+#define MLP_PARAMS (MLP_OFF_BH + 16)
+
+// one dense layer: OUT/16 output blocks, IN/4 k-steps; Wp is [mb][step][lane]
+template <int OUT_BLOCKS, int IN_BLOCKS>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ Wp, const float* __restrict__ bias, const f32x4* in, f32x4* out,
+                                          int lane, int g, bool act) {
+#pragma unroll
+  for (int mb = 0; mb < OUT_BLOCKS; mb++) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < IN_BLOCKS * 4; st++) {
+      float a = Wp[(size_t)(mb * IN_BLOCKS * 4 + st) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in[st >> 2][st & 3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { float v = acc[i] + bias[16 * mb + 4 * g + i]; acc[i] = act ? elu(v) : v; }
+    out[mb] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_mlp_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
+                                                    float* __restrict__ mean, float* __restrict__ value) {
+  const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+  const int s0 = blockIdx.x * 16;
+  const int sample = min(s0 + n, B - 1);
+  const float* ob = obs + (size_t)sample * 64;
+  const float clip = W[MLP_OFF_CLIP];
+  // layer-1 input in "k-step" form: x[st] = normalised obs[4 st + g]; stored as 4 pseudo accumulator blocks of 16 features so
+  // that the generic layer can index in[st >> 2][st & 3]
+  f32x4 x[4];
+#pragma unroll
+  for (int st = 0; st < 16; st++) {
+    int c = 4 * st + g;
+    float v = (ob[c] - W[MLP_OFF_MEAN + c]) * W[MLP_OFF_ISTD + c];
+    x[st >> 2][st & 3] = fminf(fmaxf(v, -clip), clip);
+  }
+  f32x4 h1[16], h2[8], h3[4], ho[1];
+  mlp_layer<16, 4>(W + MLP_OFF_W1, W + MLP_OFF_B1, x, h1, lane, g, true);
+  mlp_layer<8, 16>(W + MLP_OFF_W2, W + MLP_OFF_B2, h1, h2, lane, g, true);
+  mlp_layer<4, 8>(W + MLP_OFF_W3, W + MLP_OFF_B3, h2, h3, lane, g, true);
+  mlp_layer<1, 4>(W + MLP_OFF_WH, W + MLP_OFF_BH, h3, ho, lane, g, false);
+  if (s0 + n < B) {
+    if (g < 3) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) mean[(size_t)(s0 + n) * 12 + 4 * g + i] = ho[0][i];
+    } else value[s0 + n] = ho[0][0];
+  }
+}
+
 extern "C" {
+
+int lm_mlp_param_count(void) { return MLP_PARAMS; }
+
+int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
+  if (!obs || !params || !mean || !value || batch <= 0) return -1;
+  hipLaunchKernelGGL(k_mlp_forward, dim3((batch + 15) / 16), dim3(64), 0, (hipStream_t)stream, obs, batch, params, mean, value);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int lm_gnn_param_count(void) { return OFF_VAL_B + 1; }
 

@@ -22,7 +22,7 @@ PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_ST
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
            "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_set_seed", "lm_last_error", "lm_version",
-           "lm_gnn_param_count", "lm_gnn_forward"]
+           "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward"]
 
 # rows of the SoA float state
 ROW = dict(base_pos=0, base_quat=3, base_lin=7, base_ang=10, q=13, qd=25, plate_pos=37, plate_quat=40, plate_lin=44,
@@ -127,6 +127,7 @@ def load_library() -> C.CDLL:
     lib.lm_num_envs.argtypes = [vp]
     lib.lm_set_seed.argtypes = [vp, C.c_uint32]
     lib.lm_gnn_forward.argtypes = [fp, ip, fp, fp, fp, vp]
+    lib.lm_mlp_forward.argtypes = [fp, ip, fp, fp, fp, vp]
     lib.lm_last_error.restype = C.c_char_p
     lib.lm_version.restype = C.c_char_p
     _lib = lib

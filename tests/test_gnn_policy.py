@@ -92,3 +92,34 @@ def test_gnn_policy_drives_vertical_env():
         obs = o["obs"]
         assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(mean).all()
     env.close()
+
+
+def test_mlp_policy_shape_and_param_count():
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params
+    m = SharedMLP()
+    assert sum(p.numel() for p in m.parameters()) == 58649                # SURVEY Appendix F (trunk + heads + 12 log_std)
+    mean, log_std, value = m(torch.randn(5, 64))
+    assert mean.shape == (5, 12) and value.shape == (5, 1)
+    assert pack_mlp_params(m).numel() == 132 + 256 * 64 + 256 + 128 * 256 + 128 + 64 * 128 + 64 + 16 * 64 + 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [4096, 4101])
+def test_mlp_hip_forward_matches_torch(B):
+    """MFMA fp32 forward vs the eager fp32 torch modules, with and without the observation scaler (tolerance 2e-5)."""
+    from locomanipulationrl_amd.lib import build_library
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, mlp_forward_hip, pack_mlp_params
+    build_library()
+    torch.manual_seed(0)
+    m = SharedMLP().cuda()
+    obs = (torch.randn(B, 64, generator=torch.Generator().manual_seed(1)) * 2).cuda()
+    with torch.no_grad():
+        ref_mean, _, ref_value = m(obs)
+    mean, value = mlp_forward_hip(obs, pack_mlp_params(m))
+    assert (mean - ref_mean).abs().max() < 2e-5 and (value - ref_value).abs().max() < 2e-5
+    mu, var = obs.mean(0), obs.var(0)
+    with torch.no_grad():
+        xn = torch.clamp((obs - mu) / (var.sqrt() + 1e-8), -5, 5)
+        ref_mean, _, ref_value = m(xn)
+    mean, value = mlp_forward_hip(obs, pack_mlp_params(m, mu, var, 1e-8, 5.0))
+    assert (mean - ref_mean).abs().max() < 2e-5 and (value - ref_value).abs().max() < 2e-5
