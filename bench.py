@@ -68,10 +68,11 @@ def main():
     from locomanipulationrl_amd.lib import Engine
     from locomanipulationrl_amd.model.robot_model import load_model
 
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)                       # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", local_rank)
     rank, local_rank, world = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     N = ENVS_PER_GPU
     eng = Engine(load_model("quadruped_robot_v2"), [loco_params()], N, seed=42 + rank, device=str(dev))
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
@@ -93,7 +94,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
     for t in range(args.warmup):
@@ -141,7 +142,7 @@ def main():
         }
     eng.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "liblm_engine.so")
+_SO = os.environ.get("LM_ENGINE_SO", os.path.join(_CSRC, "liblm_engine.so"))     # override: kernel experiments only
 
 STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS = 90, 6, 64, 93, 12, 10, 486
 PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS = range(8)

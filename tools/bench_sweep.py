@@ -1,0 +1,30 @@
+"""Throughput of lm_step versus environment count and task family (documentation numbers, not the headline bench)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from locomanipulationrl_amd.lib import Engine
+from locomanipulationrl_amd.model.robot_model import load_model
+from locomanipulationrl_amd.utils.config import SimConfig, load_config
+from locomanipulationrl_amd.utils.task_util import task_map
+
+
+def run(task_name, N, steps=300, warmup=50):
+    task = task_map()[task_name](name=task_name, sim_config=SimConfig(load_config(task_name, num_envs=N)), env=None)
+    eng = Engine(load_model(task.model_asset), task.engine_params(), N, split_env=task.split_env(), seed=1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    pool = [torch.rand(N, 12, device="cuda", generator=g) * 2 - 1 for _ in range(16)]
+    o = (torch.empty(N, 64, device="cuda"), torch.empty(N, 93, device="cuda"), torch.empty(N, device="cuda"),
+         torch.empty(N, dtype=torch.int64, device="cuda"), torch.empty(10, device="cuda"))
+    for t in range(warmup): eng.step(pool[t % 16], None, *o)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in range(steps): eng.step(pool[t % 16], None, *o)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    return {"task": task_name, "envs": N, "us_per_step": dt * 1e6, "M_env_steps_per_s": N / dt / 1e6}
+
+
+if __name__ == "__main__":
+    for N in (1024, 4096, 8192, 16384, 32768, 65536, 131072):
+        print(json.dumps(run("QuadrupedPoseControl", N)), flush=True)
+    for tn in ("QuadrupedManipulatePlate", "JointLocomanipulation", "QuadrupedPoseControlVertical", "JointLocomanipulationVertical"):
+        print(json.dumps(run(tn, 4096)), flush=True)
