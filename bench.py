@@ -126,13 +126,20 @@ def main():
         traffic = pmc["per_launch"]["hbm_traffic_bytes"] if pmc else None
         flop_env = pmc["flop_per_env_step"] if pmc else 1.67e5
         value = world * N * args.steps / elapsed
+        # second protocol of SURVEY 8(d): zero actions (standing robots, only the 300-step timeout resets); rank 0, untimed region
+        zact = torch.zeros(N, 12, device=dev)
+        for _ in range(50): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
+        torch.cuda.synchronize(dev); tz = time.perf_counter()
+        for _ in range(500): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
+        torch.cuda.synchronize(dev); zero_rate = N * 500 / (time.perf_counter() - tz)
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
                                    "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
-                       "envs_per_gpu": N, "global_envs": world * N, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
+                       "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
+                       "zero_action_env_steps_per_s_rank0": zero_rate, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_step(+k_finalize)", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
