@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Behavioural acceptance run: train the reference's PPO recipe on the engine and log the success-rate curve.
+    python tools/train_ppo.py --task QuadrupedPoseControl --num-envs 4096 --timesteps 4800 [--policy mlp|gnn] [--out profiles/x.json]
+(multi-GPU: python -m torch.distributed.run --nproc-per-node N tools/train_ppo.py ...)"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import locomanipulationrl_amd as lm
+from locomanipulationrl_amd import distributed as D
+from locomanipulationrl_amd.train.ppo import PPO
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="QuadrupedPoseControl"); ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--timesteps", type=int, default=4800); ap.add_argument("--policy", default="mlp"); ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--out", default=""); ap.add_argument("--log-every", type=int, default=5)
+    a = ap.parse_args()
+    local = int(os.environ.get("LOCAL_RANK", "0")); torch.cuda.set_device(local)
+    rank, local, world = D.init_from_env()
+    torch.manual_seed(a.seed + rank)
+    env = lm.make_env(a.task, num_envs=a.num_envs, seed=a.seed, rank=rank, sim_device=f"cuda:{local}", rl_device=f"cuda:{local}")
+    if a.policy == "gnn":
+        from locomanipulationrl_amd.policies.graph_model import GraphPolicy
+        model = GraphPolicy().to(f"cuda:{local}"); hip = False       # the GNN kernel has no folded scaler; rollouts use torch
+    else:
+        from locomanipulationrl_amd.policies.mlp_model import SharedMLP
+        model = SharedMLP().to(f"cuda:{local}"); hip = True
+    if world > 1:
+        for p in model.parameters(): torch.distributed.broadcast(p.data, 0)
+    ppo = PPO(env, model, hip_inference=hip)
+    hist = ppo.train(a.timesteps, log_every=a.log_every, log=(lambda r: print(json.dumps(r), flush=True)) if rank == 0 else (lambda r: None))
+    if rank == 0 and a.out:
+        json.dump({"task": a.task, "num_envs": a.num_envs, "world": world, "policy": a.policy, "history": hist}, open(a.out, "w"), indent=1)
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
