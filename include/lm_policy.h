@@ -14,7 +14,8 @@ extern "C" {
 /* Number of floats in the packed parameter block:
  *   input_layer1.weight (32,16) .bias (32) | input_layer2.weight (32,4) .bias (32) |
  *   3 x { linear1.weight (32,64) .bias (32) | linear2.weight (32,32) .bias (32) } |
- *   action_layer.weight (32) .bias (1) | value action_layer.weight (32) .bias (1)          (all row-major, torch layout) */
+ *   action_layer.weight (32) .bias (1) | value action_layer.weight (32) .bias (1)          (all row-major, torch layout) |
+ *   observation preprocessor: mean (64) | 1/(sqrt(var)+eps) (64) | clip (1)   (identity: 0, 1, +inf) */
 int lm_gnn_param_count(void);
 
 /* obs: device float [batch][64] (the env's observation layout, quadruped_pose_control.py:358-371);

@@ -34,6 +34,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define OFF_ACT_B (OFF_ACT_W + 32)
 #define OFF_VAL_W (OFF_ACT_B + 1)
 #define OFF_VAL_B (OFF_VAL_W + 32)
+#define OFF_OBS_MEAN (OFF_VAL_B + 1)   // observation preprocessor (skrl RunningStandardScaler): mean 64, inverse std 64, clip 1
+#define OFF_OBS_ISTD (OFF_OBS_MEAN + 64)
+#define OFF_OBS_CLIP (OFF_OBS_ISTD + 64)
+#define GNN_PARAMS (OFF_OBS_CLIP + 1)
 
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
 
@@ -49,7 +53,10 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
   const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
   const int s0 = blockIdx.x * GNN_SAMPLES;
   const int sample = min(s0 + n, B - 1);
-  const float* ob = obs + (size_t)sample * 64;
+  const float* obr = obs + (size_t)sample * 64;
+  const float oclip = W[OFF_OBS_CLIP];
+  // normalised observation column c of this lane's sample
+  auto ob = [&](int c) { float v = (obr[c] - W[OFF_OBS_MEAN + c]) * W[OFF_OBS_ISTD + c]; return fminf(fmaxf(v, -oclip), oclip); };
 
   f32x4 h[GNN_NODES][2];            // node features, C layout: h[node][mb][i] = feature 16 mb + 4 g + i of sample n
   // ---- input layers (:97-104)
@@ -61,7 +68,7 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         float a = W[OFF_IN1_W + (16 * mb + n) * 16 + 4 * s + g];
-        float b = ob[4 * s + g];
+        float b = ob(4 * s + g);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -72,7 +79,7 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
     float a2[2] = {W[OFF_IN2_W + (n) * 4 + g], W[OFF_IN2_W + (16 + n) * 4 + g]};
 #pragma unroll
     for (int nd = 1; nd < GNN_NODES; nd++) {
-      float b = (g == 0) ? ob[joint_col(nd, 0)] : (g == 1) ? ob[joint_col(nd, 1)] : (g == 2) ? ob[joint_col(nd, 2)] : ob[joint_col(nd, 3)];
+      float b = ob(joint_col(nd, 0) + 12 * g);        // feature g of the joint: columns 16+j, 28+j, 40+j, 52+j
 #pragma unroll
       for (int mb = 0; mb < 2; mb++) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -261,7 +268,7 @@ int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int lm_gnn_param_count(void) { return OFF_VAL_B + 1; }
+int lm_gnn_param_count(void) { return GNN_PARAMS; }
 
 int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
   if (!obs || !params || !mean || !value || batch <= 0) return -1;

@@ -89,13 +89,17 @@ class Value_Layer(nn.Module):
         return self.action_layer(torch.max(inp, dim=1).values)
 
 
-def pack_gnn_params(net: GraphNet, mean_layer: Action_Layer, value_layer: Value_Layer) -> torch.Tensor:
-    """Flatten the parameters in the order include/lm_policy.h documents."""
+def pack_gnn_params(net: GraphNet, mean_layer: Action_Layer, value_layer: Value_Layer, obs_mean=None, obs_var=None, eps=1e-8, clip=5.0) -> torch.Tensor:
+    """Flatten the parameters in the order include/lm_policy.h documents (optionally with the observation scaler folded in)."""
     assert net.hidden_features == 32, "the matrix-core kernel is built for hidden_features = 32"
     parts = [net.input_layer1.weight, net.input_layer1.bias, net.input_layer2.weight, net.input_layer2.bias]
     for gl in (net.graph_layer1, net.graph_layer2, net.graph_layer3):
         parts += [gl.linear1.weight, gl.linear1.bias, gl.linear2.weight, gl.linear2.bias]
     parts += [mean_layer.action_layer.weight, mean_layer.action_layer.bias, value_layer.action_layer.weight, value_layer.action_layer.bias]
+    dev = net.input_layer1.weight.device
+    parts += [torch.zeros(64, device=dev) if obs_mean is None else obs_mean.to(dev),
+              torch.ones(64, device=dev) if obs_var is None else 1.0 / (obs_var.to(dev).float().sqrt() + eps),
+              torch.tensor([clip if obs_var is not None else 3.0e38], device=dev)]
     return torch.cat([p.detach().reshape(-1).float() for p in parts]).contiguous()
 
 
@@ -137,5 +141,5 @@ class GraphPolicy(nn.Module):
         mean, value = gnn_forward_hip(obs, self._packed)
         return mean, self.log_std_parameter, value
 
-    def refresh(self, device=None):
-        self._packed = pack_gnn_params(self.net, self.mean_layer, self.value_layer).to(device or self.log_std_parameter.device)
+    def refresh(self, device=None, obs_mean=None, obs_var=None, eps=1e-8, clip=5.0):
+        self._packed = pack_gnn_params(self.net, self.mean_layer, self.value_layer, obs_mean, obs_var, eps, clip).to(device or self.log_std_parameter.device)

@@ -52,7 +52,7 @@ def test_torch_modules_are_state_dict_compatible_with_reference(golden):
 
 def test_param_packing_size(golden):
     net, act, val = load_modules(golden)
-    assert pack_gnn_params(net, act, val).numel() == 704 + 3 * 3136 + 66
+    assert pack_gnn_params(net, act, val).numel() == 704 + 3 * 3136 + 66 + 129
 
 
 @pytest.mark.gpu
@@ -77,6 +77,11 @@ def test_hip_forward_matches_reference_and_oracle(golden, B):
     with torch.no_grad():
         h = net.cuda()(obs)
         assert (act.cuda()(h) - mean).abs().max() < 1e-5 and (val.cuda()(h) - value).abs().max() < 1e-5
+        # with the observation scaler folded into the kernel
+        mu, var = obs.mean(0), obs.var(0)
+        m2, v2 = gnn_forward_hip(obs.contiguous(), pack_gnn_params(net, act, val, mu, var, 1e-8, 5.0))
+        h2 = net(torch.clamp((obs - mu) / (var.sqrt() + 1e-8), -5, 5))
+        assert (act(h2) - m2).abs().max() < 1e-5 and (val(h2) - v2).abs().max() < 1e-5
 
 
 @pytest.mark.gpu
