@@ -42,7 +42,7 @@ extern "C" {
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
  * sources in the reference are cited there. */
 typedef struct lm_params {
-  float dt, kd, tau_max, act_scale, mu, tip_radius, baumgarte, max_depen_vel, gravity;
+  float dt, kd, tau_max, act_scale, mu, tip_radius, baumgarte, max_depen_vel, max_joint_vel, gravity;
   int32_t substeps, pgs_iters, mode;
   float fixed_base_pos[3], fixed_base_quat[4];
   float plate_mass, plate_com[3], plate_inertia[3], plate_half[3], plate_center[3];

@@ -462,7 +462,10 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     }
   }
 #pragma unroll
-  for (int a = 0; a < 3; a++) { qd[a] = qdn[a]; q[a] = fmaf(dt, qdn[a], q[a]); }
+  for (int a = 0; a < 3; a++) {      // driven joints are speed-limited like PhysX's maxJointVelocity (config_module_joints.py:11,61-69)
+    float v = fminf(fmaxf(qdn[a], -P->max_joint_vel), P->max_joint_vel);
+    qd[a] = v; q[a] = fmaf(dt, v, q[a]);
+  }
   F.u = un;
   integrate_free(F, Rf, dt);
 }

@@ -44,6 +44,7 @@ class EngineParams:
     tip_radius: float = 0.002
     baumgarte: float = 0.2
     max_depen_vel: float = 1.0
+    max_joint_vel: float = 7.853981633974483     # 450 deg/s: physxJoint:maxJointVelocity set by Design/Scripts/config_module_joints.py:11,61-69
     mode: int = MODE_LOCO
     fixed_base_pos: List[float] = _f([0.0, 0.0, 0.0])
     fixed_base_quat: List[float] = _f([0.0, 1.0, 0.0, 0.0])

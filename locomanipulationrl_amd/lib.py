@@ -33,7 +33,7 @@ CNT = dict(successes=0, consecutive_successes=1, goal_reset_buf=2, reset_buf=3, 
 class LmParams(C.Structure):
     _fields_ = [
         ("dt", C.c_float), ("kd", C.c_float), ("tau_max", C.c_float), ("act_scale", C.c_float), ("mu", C.c_float),
-        ("tip_radius", C.c_float), ("baumgarte", C.c_float), ("max_depen_vel", C.c_float), ("gravity", C.c_float),
+        ("tip_radius", C.c_float), ("baumgarte", C.c_float), ("max_depen_vel", C.c_float), ("max_joint_vel", C.c_float), ("gravity", C.c_float),
         ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("mode", C.c_int32),
         ("fixed_base_pos", C.c_float * 3), ("fixed_base_quat", C.c_float * 4),
         ("plate_mass", C.c_float), ("plate_com", C.c_float * 3), ("plate_inertia", C.c_float * 3),

@@ -93,6 +93,7 @@ class _QuadrupedTask(RLTask):
             kd=float(rd.joint_kds[0]), tau_max=float(rd.torque_limits[0]), act_scale=float(rd.velocity_limits[0]), mu=mu,
             tip_radius=float(eng.get("tip_radius", 0.002)), baumgarte=float(eng.get("baumgarte", 0.2)),
             max_depen_vel=float(eng.get("max_depenetration_velocity", 1.0)),
+            max_joint_vel=float(eng.get("max_joint_velocity_deg", 450.0)) * 3.141592653589793 / 180.0,
             init_q=list(rd.init_joint_pos[:12]),
             goal_lo=[self.min_roll, self.min_pitch, self.min_yaw], goal_hi=[self.max_roll, self.max_pitch, self.max_yaw],
             s_pos=float(self.ground_position_scale), s_lin=float(self.ground_linear_vel_scale), s_ang=float(self.ground_angular_vel_scale),

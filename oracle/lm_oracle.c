@@ -312,8 +312,8 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); if (tau>tmax){sat[j]=1;tsat[j]=tmax;any=1;} else if (tau<-tmax){sat[j]=1;tsat[j]=-tmax;any=1;} }
       if (!any) break; }
   }
-  /* integrate */
-  for (int j=0;j<12;j++) { phys[25+j]=un[6+j]; phys[13+j]+=dt*un[6+j]; }
+  /* integrate; driven joints are speed-limited like PhysX's maxJointVelocity (Design/Scripts/config_module_joints.py:11,61-69) */
+  for (int j=0;j<12;j++) { real v=un[6+j]; real vm=(real)p->max_joint_vel; if (v>vm) v=vm; if (v<-vm) v=-vm; phys[25+j]=v; phys[13+j]+=dt*v; }
   {
     real* pos  = (p->mode==0)? phys   : phys+37;
     real* quat = (p->mode==0)? phys+3 : phys+40;

@@ -69,6 +69,7 @@ typedef struct {
   double tip_radius;
   double baumgarte;          /* penetration push-out fraction per step */
   double max_depen_vel;      /* m/s cap on push-out */
+  double max_joint_vel;      /* rad/s clamp on the driven joints' speed (USD maxJointVelocity 450 deg/s) */
   int32_t mode;              /* 0 = free base on ground (loco), 1 = fixed inverted base + plate (mani) */
   int32_t pad0;
   double fixed_base_pos[3];

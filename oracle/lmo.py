@@ -31,7 +31,7 @@ class LmoParams(C.Structure):
     _fields_ = [
         ("dt", C.c_double), ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("gravity", C.c_double),
         ("kd", C.c_double), ("tau_max", C.c_double), ("act_scale", C.c_double), ("mu", C.c_double),
-        ("tip_radius", C.c_double), ("baumgarte", C.c_double), ("max_depen_vel", C.c_double),
+        ("tip_radius", C.c_double), ("baumgarte", C.c_double), ("max_depen_vel", C.c_double), ("max_joint_vel", C.c_double),
         ("mode", C.c_int32), ("pad0", C.c_int32),
         ("fixed_base_pos", C.c_double * 3), ("fixed_base_quat", C.c_double * 4),
         ("plate_mass", C.c_double), ("plate_com", C.c_double * 3), ("plate_inertia", C.c_double * 3),
