@@ -91,6 +91,21 @@ class EngineParams:
     h_knee: float = 0.04
     corner: List[List[float]] = field(default_factory=lambda: [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04],
                                                                [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]])
+    # ---- custom-controller task family (quadruped_pose_control_custom_controller.py:24-52,88-97)
+    variant: int = 0                    # 0 velocity-drive tasks, 1 custom-controller (PD actuator, swing/extension actions, obs 88)
+    num_obs: int = 64
+    pd_kp: float = 4.5
+    joint_damping: float = 0.0
+    act_scale_se: float = 0.1
+    se_lo: List[float] = _f([-2.35, -0.78, -0.78, -2.35, -2.09, 0.52, 1.05, 0.52, 1.05, 0.52, -2.09, 0.52])
+    se_hi: List[float] = _f([0.78, 2.35, 2.35, 0.78, -1.05, 2.09, 2.09, 2.09, 2.09, 2.09, -1.05, 2.09])
+    init_se: List[float] = _f([-1.2, 1.2, 1.2, -1.2, -1.57, 0.7, 1.57, 0.7, 1.57, 0.7, -1.57, 0.7])
+    torque_div: float = 4.0
+    power_scale: float = -0.02
+    target_err_scale: float = -0.05
+    rot_dec_scale: float = 0.0
+    rot_dec_thresh: float = 0.3
+    cc_update_last_tgt: int = 1         # loco: last targets follow the targets (:723-725); the mani variant never updates them after reset
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 
@@ -108,3 +123,27 @@ def mani_params(**kw) -> EngineParams:
     """Horizontal manipulation task (QuadrupedManipulatePlate): fixed inverted base at the origin,
     plate dropped from z = 0.14 (quadruped_manipulate_plate.py:91-94,150-151)."""
     return replace(EngineParams(mode=MODE_MANI), **kw)
+
+
+_CLASS_DEFAULT_Q = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]      # robot/quadruped_robot.py:45-52
+
+
+def _cc(**kw):
+    """Constants shared by the custom-controller tasks (quadruped_pose_control_custom_controller.py:24-52,88-108;
+    cfg/task/QuadrupedPoseControlCustomController.yaml:13,18-19: dt 0.005, controlFrequencyInv 1, 500-step episodes;
+    control_decimal 4 in-task sub-steps + 1 wrapper step = 5 sub-steps per action)."""
+    base = dict(variant=1, num_obs=88, dt=0.005, substeps=5, kd=0.2, pd_kp=4.5, joint_damping=0.008, tau_max=1.5, act_scale_se=0.1,
+                torque_div=4.0, init_q=list(_CLASS_DEFAULT_Q), acc_scale=-0.00015, rate_scale=-0.01, max_consec=20, max_episode=500,
+                power_scale=-0.02, target_err_scale=-0.05, rot_dec_scale=0.0, rot_dec_thresh=0.3)
+    base.update(kw)
+    return base
+
+
+def loco_cc_params(**kw) -> EngineParams:
+    """QuadrupedPoseControlCustomController: class-default pose, base at z 0.18, fixed goal yaw 1.57 (:67-78)."""
+    return replace(EngineParams(), **_cc(init_base_pos=[0.0, 0.0, 0.18], goal_lo=[0.0, 0.0, 1.57], goal_hi=[0.0, 0.0, 1.57], **kw))
+
+
+def mani_cc_params(**kw) -> EngineParams:
+    """QuadrupedManipulatePlateCustomController: plate dropped from z 0.18 onto the inverted fixed robot."""
+    return replace(EngineParams(mode=MODE_MANI), **_cc(init_plate_pos=[0.0, 0.0, 0.18], cc_update_last_tgt=0, **kw))

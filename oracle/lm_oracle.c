@@ -258,10 +258,10 @@ static void chol_solve(real L[NU][NU], const real* b, real* x) {
 /* debug capture of the contact problem of the LAST pass executed (tests / solver studies) */
 static __thread real* g_cap_W = 0; static __thread real* g_cap_vf = 0; static __thread real* g_cap_bn = 0; static __thread real* g_cap_lam = 0;
 
-static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, const real* target) {
+static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, const real* target, real* tau_out) {
   dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t));
   dyn_compute(m, p, phys, D);
-  const real dt=(real)p->dt, kd=(real)p->kd, tmax=(real)p->tau_max, mu=(real)p->mu;
+  const real dt=(real)p->dt, kd=(real)p->kd, tmax=(real)p->tau_max, mu=(real)p->mu, cj=(real)p->joint_damping;
   real u[NU];
   if (p->mode==0) { m3Tv(D->R0, phys+10, u); m3Tv(D->R0, phys+7, u+3); }
   else { m3Tv(D->Rf, phys+47, u); m3Tv(D->Rf, phys+44, u+3); }
@@ -293,7 +293,8 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
   for (int pass=0; pass<2; pass++) {
     real L[NU][NU]; memcpy(L, D->M, sizeof(L)); real rhs[NU];
     for (int a=0;a<NU;a++) rhs[a]=-D->h[a];
-    for (int j=0;j<12;j++) { if (!sat[j]) { L[6+j][6+j]+=dt*kd; rhs[6+j]+=kd*(target[j]-u[6+j]); } else rhs[6+j]+=tsat[j]; }
+    for (int j=0;j<12;j++) { if (!sat[j]) { L[6+j][6+j]+=dt*kd; rhs[6+j]+=kd*(target[j]-u[6+j]); } else rhs[6+j]+=tsat[j];
+      L[6+j][6+j]+=dt*cj; rhs[6+j]-=cj*u[6+j]; }       /* viscous joint damping, implicit */
     chol(L);
     real acc[NU], uf[NU]; chol_solve(L, rhs, acc); for (int a=0;a<NU;a++) uf[a]=u[a]+dt*acc[a];
     real MiJ[12][NU], W[12][12], vf[12], lam[12];
@@ -312,6 +313,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); if (tau>tmax){sat[j]=1;tsat[j]=tmax;any=1;} else if (tau<-tmax){sat[j]=1;tsat[j]=-tmax;any=1;} }
       if (!any) break; }
   }
+  if (tau_out) for (int j=0;j<12;j++) tau_out[j] = sat[j] ? tsat[j] : kd*(target[j]-un[6+j]);   /* drive torque applied over this sub-step */
   /* integrate; driven joints are speed-limited like PhysX's maxJointVelocity (Design/Scripts/config_module_joints.py:11,61-69) */
   for (int j=0;j<12;j++) { real v=un[6+j]; real vm=(real)p->max_joint_vel; if (v>vm) v=vm; if (v<-vm) v=-vm; phys[25+j]=v; phys[13+j]+=dt*v; }
   {
@@ -335,13 +337,18 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
 void lmo_contact_problem(const lmo_model* m, const lmo_params* p, const real* phys, const real* target, real* W, real* vf, real* bn, real* lam) {
   real ph[LMO_PHYS]; memcpy(ph, phys, sizeof(ph));
   g_cap_W=W; g_cap_vf=vf; g_cap_bn=bn; g_cap_lam=lam;
-  substep_one(m, p, ph, target);
+  substep_one(m, p, ph, target, NULL);
   g_cap_W=0; g_cap_vf=0; g_cap_bn=0; g_cap_lam=0;
 }
 
 void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets) {
   #pragma omp parallel for schedule(static)
-  for (int e=0;e<N;e++) substep_one(m, p, phys+(size_t)e*LMO_PHYS, targets+(size_t)e*12);
+  for (int e=0;e<N;e++) substep_one(m, p, phys+(size_t)e*LMO_PHYS, targets+(size_t)e*12, NULL);
+}
+
+void lmo_substep_tau(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets, real* tau) {
+  #pragma omp parallel for schedule(static)
+  for (int e=0;e<N;e++) substep_one(m, p, phys+(size_t)e*LMO_PHYS, targets+(size_t)e*12, tau+(size_t)e*12);
 }
 
 /* ------------------------------------------------------------------ task layer */
@@ -353,7 +360,10 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
   for (int e=0;e<N;e++) {
     const real* rb=readback+(size_t)e*LMO_READBACK; const real* act=actions+(size_t)e*12;
     real* tk=task+(size_t)e*LMO_TASK; int64_t* c=cnt+(size_t)e*LMO_CNT;
-    real* ob=obs+(size_t)e*64; real* st=states+(size_t)e*93; real* tr=terms+(size_t)e*LMO_TERMS;
+    real* ob=obs+(size_t)e*p->num_obs; real* st=states+(size_t)e*93; real* tr=terms+(size_t)e*LMO_TERMS;
+    const int var1=(p->variant==1); const real* torque=rb+87; real* se=tk+40; real* last_tgt=tk+52;
+    real tgtq[12];   /* current joint position targets from the swing/extension targets (:267-276) */
+    for (int l=0;l<4;l++) { tgtq[l]=se[l]; tgtq[4+2*l]=se[4+2*l]+se[5+2*l]/2; tgtq[5+2*l]=se[4+2*l]-se[5+2*l]/2; }
     const real *q=rb, *qd=rb+12, *acc=rb+24, *bp=rb+36, *bq=rb+39, *lv=rb+43, *av=rb+46, *tips=rb+49, *knees=rb+61;
     real* last_act=tk; real* last_tip=tk+24; real* goal=tk+36;
     /* post_physics_step: progress_buf += 1 (rl_task.py:251) */
@@ -375,7 +385,7 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     }
     for (int i=0;i<4;i++) { real d[3]={tips[3*i]-pr[0],tips[3*i+1]-pr[1],tips[3*i+2]-pr[2]}; m3Tv(Rr, d, btip+3*i); }
     real gc[4], qdiff[4]; quat_conj(goal, gc); quat_mul(oquat, gc, qdiff);
-    real qdf[4]; for (int i=0;i<4;i++) qdf[i]=(qdiff[0]<0)?-qdiff[i]:qdiff[i];
+    real qdf[4]; for (int i=0;i<4;i++) qdf[i]=(qdiff[0]<0 && !var1)?-qdiff[i]:qdiff[i];   /* the custom-controller tasks do not flip the sign (:429-431) */
     real Ro[9]; quat_to_mat(oquat, Ro); real up[3]={Ro[2],Ro[5],Ro[8]};
     int k=0;
     for (int i=0;i<3;i++) ob[k++]=(real)p->s_pos*opos[i];
@@ -387,6 +397,7 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     for (int i=0;i<12;i++) ob[k++]=(real)p->s_qd*qd[i];
     for (int i=0;i<12;i++) ob[k++]=act[i];
     for (int i=0;i<12;i++) ob[k++]=last_act[i];
+    if (var1) { for (int i=0;i<12;i++) ob[k++]=(real)0.3*tgtq[i]; for (int i=0;i<12;i++) ob[k++]=(real)0.3*last_tgt[i]; }   /* :432-455 */
     k=0;
     for (int i=0;i<3;i++) st[k++]=(real)p->s_pos*opos[i];
     for (int i=0;i<3;i++) st[k++]=(real)p->s_lin*olin[i];
@@ -406,7 +417,13 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     real rot_dist=2*asin(vn);
     real rot_rew=(real)p->quat_scale/(fabs(rot_dist)+(real)p->rot_eps);
     real trans=sqrt(opos[0]*opos[0]+opos[1]*opos[1])*(real)p->trans_scale;
-    real accp=0, rate=0; for (int i=0;i<12;i++){ accp+=fabs(acc[i])*(real)p->acc_scale; rate+=fabs(last_act[i]-act[i]); } rate*=(real)p->rate_scale;
+    real accp=0, rate=0; for (int i=0;i<12;i++){ accp+=fabs(acc[i])*(real)p->acc_scale; rate+=var1?fabs(act[i]):fabs(last_act[i]-act[i]); } rate*=(real)p->rate_scale;
+    real powp=0, terr=0, rdec=0;
+    if (var1) {   /* :530-545 */
+      for (int i=0;i<12;i++){ powp+=fabs(torque[i]*qd[i]); terr+=fabs(last_tgt[i]-q[i]); }
+      powp*=(real)p->power_scale; terr*=(real)p->target_err_scale;
+      rdec=((rot_dist>(real)p->rot_dec_thresh)?(real)1:(real)0)*(tk[64]-rot_dist)*(real)p->rot_dec_scale; tk[64]=rot_dist;
+    }
     int64_t cgr=(c[1]>p->max_consec)?1:0;
     real bonus=(real)p->bonus*(real)cgr;
     int64_t succ=(fabs(rot_dist)<=(real)p->succ_thresh)?1:0;
@@ -419,7 +436,7 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
       if (q[l]<(real)p->d1_rst[l][0]||q[l]>(real)p->d1_rst[l][1]) rst++;
     }
     real limp=(brk>0)?(real)p->limit_pen:0;
-    real total=rot_rew+trans+accp+rate+bonus+limp;
+    real total=rot_rew+trans+accp+rate+bonus+limp+powp+terr+rdec;
     c[2]=cgr;
     int64_t both=(succ&&c[0])?1:0;
     if (!both) c[1]=0; else c[1]=c[1]+1;
@@ -454,7 +471,8 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     if (c[4]>=p->max_episode-1) reset=1;
     c[3]=reset;
     rew[e]=total;
-    tr[0]=rot_rew; tr[1]=trans; tr[2]=accp; tr[3]=rate; tr[4]=bonus; tr[5]=limp; tr[6]=fallp; tr[7]=(real)cgr;
+    tr[0]=rot_rew; tr[1]=trans; tr[2]=accp; tr[3]=rate; tr[4]=bonus; tr[5]=limp; tr[6]=fallp; tr[7]=(real)cgr; tr[8]=powp; tr[9]=terr; tr[10]=rdec;
+    if (var1 && p->cc_update_last_tgt) for (int i=0;i<12;i++) last_tgt[i]=tgtq[i];     /* :723-725, end of is_done */
   }
 }
 
@@ -473,6 +491,13 @@ void lmo_reset(const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
     for (int i=0;i<12;i++) { ph[13+i]=(real)p->init_q[i]; ph[25+i]=0; tk[i]=0; tk[12+i]=0; tk[24+i]=(real)p->default_tip[i]; }
     for (int i=0;i<3;i++) { ph[i]=(real)p->init_base_pos[i]; ph[7+i]=0; ph[10+i]=0; ph[37+i]=(real)p->init_plate_pos[i]; ph[44+i]=0; ph[47+i]=0; }
     for (int i=0;i<4;i++) { ph[3+i]=(real)p->init_base_quat[i]; ph[40+i]=(real)p->init_plate_quat[i]; }
+    if (p->variant==1) {   /* :371-384 */
+      for (int i=0;i<12;i++) { tk[40+i]=(real)p->init_se[i]; tk[52+i]=(real)p->init_q[i]; }
+      real qb[4]={(real)p->init_base_quat[0],-(real)p->init_base_quat[1],-(real)p->init_base_quat[2],-(real)p->init_base_quat[3]}, gc[4], qd4[4];
+      if (p->mode==1) { qb[0]=1; qb[1]=qb[2]=qb[3]=0; }
+      quat_conj(tk+36, gc); quat_mul(qb, gc, qd4);
+      real vn=sqrt(qd4[1]*qd4[1]+qd4[2]*qd4[2]+qd4[3]*qd4[3]); if (vn>1) vn=1; tk[64]=2*asin(vn);
+    }
     c[0]=0; c[1]=0; c[2]=0; c[3]=0; c[4]=0; c[5]+=1;
   }
 }
@@ -483,9 +508,26 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
   lmo_reset(p, N, phys, task, cnt, goal_rand, seed);
   real* targets=(real*)malloc(sizeof(real)*12*(size_t)N);
   real* rb=(real*)malloc(sizeof(real)*LMO_READBACK*(size_t)N);
-  /* robot.py:452-454: velocity mode, unscale_transform(a, -lim, +lim) = a*lim */
-  for (size_t i=0;i<(size_t)N*12;i++) targets[i]=actions[i]*(real)p->act_scale;
-  for (int s=0;s<p->substeps;s++) lmo_substep(m, p, N, phys, targets);
+  real* tausum=(real*)calloc((size_t)N*12, sizeof(real));
+  if (p->variant==0) {
+    /* robot.py:452-454: velocity mode, unscale_transform(a, -lim, +lim) = a*lim */
+    for (size_t i=0;i<(size_t)N*12;i++) targets[i]=actions[i]*(real)p->act_scale;
+    for (int s=0;s<p->substeps;s++) lmo_substep(m, p, N, phys, targets);
+  } else {
+    /* quadruped_pose_control_custom_controller.py:255-307: integrate swing/extension targets, PD torque every sub-step */
+    real* tau=(real*)malloc(sizeof(real)*12*(size_t)N);
+    for (int e=0;e<N;e++) { real* se=task+(size_t)e*LMO_TASK+40;
+      for (int i=0;i<12;i++) { real v=se[i]+actions[(size_t)e*12+i]*(real)p->act_scale_se; if (v<(real)p->se_lo[i]) v=(real)p->se_lo[i]; if (v>(real)p->se_hi[i]) v=(real)p->se_hi[i]; se[i]=v; } }
+    for (int s=0;s<p->substeps;s++) {
+      for (int e=0;e<N;e++) { const real* se=task+(size_t)e*LMO_TASK+40; const real* q=phys+(size_t)e*LMO_PHYS+13; real* tg=targets+(size_t)e*12; real qs[12];
+        for (int l=0;l<4;l++) { qs[l]=se[l]; qs[4+2*l]=se[4+2*l]+se[5+2*l]/2; qs[5+2*l]=se[4+2*l]-se[5+2*l]/2; }
+        /* tau = kp (q* - q) - kd qd  ==  kd (v* - qd)  with  v* = kp/kd (q* - q): the velocity-drive solver with a position-derived target */
+        for (int i=0;i<12;i++) tg[i]=(real)p->pd_kp/(real)p->kd*(qs[i]-q[i]); }
+      lmo_substep_tau(m, p, N, phys, targets, tau);
+      for (size_t i=0;i<(size_t)N*12;i++) tausum[i]+=tau[i];
+    }
+    free(tau);
+  }
   #pragma omp parallel for schedule(static)
   for (int e=0;e<N;e++) {
     real* ph=phys+(size_t)e*LMO_PHYS; real* tk=task+(size_t)e*LMO_TASK; real* r=rb+(size_t)e*LMO_READBACK;
@@ -495,7 +537,8 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
     const real* src=(p->mode==0)?ph:ph+37;
     for (int i=0;i<13;i++) r[36+i]=src[i];
     lmo_fk(m, p, ph, r+49, r+61); r[85]=r[86]=0;
+    for (int i=0;i<12;i++) r[87+i]=(p->variant==1)?tausum[(size_t)e*12+i]/(real)p->torque_div:0;
   }
   lmo_task_eval(p, N, rb, actions, task, cnt, obs, states, rew, terms);
-  free(targets); free(rb);
+  free(targets); free(rb); free(tausum);
 }

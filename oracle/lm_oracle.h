@@ -99,23 +99,39 @@ typedef struct {
   double h_base, h_corner, h_knee;
   double corner[4][3];       /* frame corner points in the robot base frame */
   double ctrl_dt;            /* dt*substeps, for joint acceleration */
+  /* ---- custom-controller task family (quadruped_pose_control_custom_controller.py:24-52,255-307,530-545):
+   * actions integrate swing/extension position targets, the actuator is  tau = clamp(kp (q* - q) - kd qd, +-tau_max)
+   * re-evaluated every sub-step (kd above is its damping gain), plus viscous joint damping */
+  int32_t variant;           /* 0 = velocity-drive tasks, 1 = custom-controller tasks */
+  int32_t num_obs;           /* 64 or 88 */
+  double pd_kp;              /* 4.5 */
+  double joint_damping;      /* 0.008 (0 for variant 0) */
+  double act_scale_se;       /* 0.1 */
+  double se_lo[12], se_hi[12], init_se[12];
+  double torque_div;         /* control_decimal: the logged torque is sum over sub-steps / control_decimal (:307) */
+  double power_scale, target_err_scale, rot_dec_scale, rot_dec_thresh;
+  int32_t cc_update_last_tgt;  /* 1: last_joint_position_targets follows the targets (loco, :723-725); 0: stays at its reset value
+                                  (quadruped_manipulate_plate_custom_controller.py never updates it after :378) */
+  int32_t pad1;
 } lmo_params;
 
 /* per-env physical state, env-major */
 #define LMO_PHYS 50
 /*  0:3 base_pos  3:7 base_quat(wxyz)  7:10 base_linvel(world) 10:13 base_angvel(world)
  * 13:25 q  25:37 qd  37:40 plate_pos 40:44 plate_quat 44:47 plate_linvel 47:50 plate_angvel */
-#define LMO_TASK 40
-/*  0:12 last_actions 12:24 last_qd 24:36 last_base_tip 36:40 goal_quat */
+#define LMO_TASK 65
+/*  0:12 last_actions 12:24 last_qd 24:36 last_base_tip 36:40 goal_quat
+ *  40:52 swing/extension targets 52:64 last joint position targets 64 last_rot_dist   (variant 1) */
 #define LMO_CNT 6
 /*  successes, consecutive_successes, goal_reset_buf, reset_buf, progress_buf, episode_count */
-#define LMO_READBACK 87
+#define LMO_READBACK 99
 /*  0:12 q 12:24 qd 24:36 acc 36:39 base_pos 39:43 base_quat 43:46 linvel 46:49 angvel
- *  49:61 tips(4x3) 61:85 knees(8x3) 85:87 unused
+ *  49:61 tips(4x3) 61:85 knees(8x3) 85:87 unused 87:99 logged joint torque (variant 1)
  *  (mani: base_* slots hold the plate pose/velocity; robot pose is params.fixed_base_*) */
-#define LMO_TERMS 8
+#define LMO_TERMS 11
 /*  rot_rew, translation_penalty, joint_acc_penalty, action_rate_penalty,
- *  consecutive_successes_rew, joint_limit_penalty, fall_penalty, goal_reset (as real) */
+ *  consecutive_successes_rew, joint_limit_penalty, fall_penalty, goal_reset (as real),
+ *  mechanical_power_penalty, position_target_error_penalty, rot_dist_decreasing_reward */
 
 #ifdef __cplusplus
 extern "C" {
@@ -126,6 +142,8 @@ void lmo_fk(const lmo_model* m, const lmo_params* p, const real* phys, real* tip
 
 /* one physics sub-step for N envs; targets = joint velocity targets (N x 12) */
 void lmo_substep(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets);
+/* same, also returning the drive torque applied in that sub-step (N x 12) */
+void lmo_substep_tau(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets, real* tau);
 
 /* contact problem of one env's next sub-step: Delassus W (12x12), free contact velocities vf (12), normal biases bn (4)
  * and the PGS impulses lam (12) -- for solver-convergence studies and tests */

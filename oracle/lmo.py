@@ -13,7 +13,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 MAXB, NTREE, NQ = 24, 20, 12
-PHYS, TASK, CNT, READBACK, TERMS = 50, 40, 6, 87, 8
+PHYS, TASK, CNT, READBACK, TERMS = 50, 65, 6, 99, 11
 
 
 class LmoModel(C.Structure):
@@ -47,6 +47,9 @@ class LmoParams(C.Structure):
         ("d1_pen", (C.c_double * 2) * 4), ("d1_rst", (C.c_double * 2) * 4),
         ("h_base", C.c_double), ("h_corner", C.c_double), ("h_knee", C.c_double),
         ("corner", (C.c_double * 3) * 4), ("ctrl_dt", C.c_double),
+        ("variant", C.c_int32), ("num_obs", C.c_int32), ("pd_kp", C.c_double), ("joint_damping", C.c_double), ("act_scale_se", C.c_double),
+        ("se_lo", C.c_double * 12), ("se_hi", C.c_double * 12), ("init_se", C.c_double * 12), ("torque_div", C.c_double),
+        ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("pad1", C.c_int32),
     ]
 
 
@@ -89,7 +92,7 @@ def make_model(rm) -> LmoModel:
 def make_params(ep) -> LmoParams:
     p = LmoParams()
     for name, ctype in LmoParams._fields_:
-        if name == "pad0":
+        if name in ("pad0", "pad1"):
             continue
         val = getattr(ep, name)
         if isinstance(val, (list, tuple, np.ndarray)):
@@ -152,7 +155,7 @@ class Oracle:
         N = readback.shape[0]
         readback = self._arr(readback, (N, READBACK)); actions = self._arr(actions, (N, 12))
         assert task.dtype == self.dtype and cnt.dtype == np.int64
-        obs = np.zeros((N, 64), self.dtype); states = np.zeros((N, 93), self.dtype)
+        obs = np.zeros((N, self._ep.num_obs), self.dtype); states = np.zeros((N, 93), self.dtype)
         rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype)
         self.lib.lmo_task_eval(C.byref(self.params), C.c_int(N), self._p(readback), self._p(actions), self._p(task),
                                self._p(cnt), self._p(obs), self._p(states), self._p(rew), self._p(terms))
@@ -168,7 +171,7 @@ class Oracle:
         N = phys.shape[0]
         actions = self._arr(actions, (N, 12))
         gr = None if goal_rand is None else self._arr(goal_rand, (N, 3))
-        obs = np.zeros((N, 64), self.dtype); states = np.zeros((N, 93), self.dtype)
+        obs = np.zeros((N, self._ep.num_obs), self.dtype); states = np.zeros((N, 93), self.dtype)
         rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype)
         self.lib.lmo_step(C.byref(self.model), C.byref(self.params), C.c_int(N), self._p(phys), self._p(task), self._p(cnt),
                           self._p(actions), None if gr is None else self._p(gr), C.c_uint32(seed),

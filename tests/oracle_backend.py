@@ -17,10 +17,11 @@ class OracleEngine:
         self.seed, self.clip_obs, self.clip_actions = seed, clip_obs, clip_actions
         o = self.oracles[0]
         self.phys, self.task, self.cntv = o.new_state(self.N)
-        self.state = torch.zeros((90, self.N), dtype=torch.float32)
+        self.state = torch.zeros((115, self.N), dtype=torch.float32)
         self.cnt = torch.zeros((6, self.N), dtype=torch.int64)
-        self.obs_buf = torch.zeros((self.N, 64)); self.states_buf = torch.zeros((self.N, 93)); self.rew_buf = torch.zeros(self.N)
-        self.extras_buf = torch.zeros(10); self.terms = torch.zeros((8, self.N)); self.stats_i64 = torch.zeros(6, dtype=torch.int64)
+        self.num_obs = self.params[0].num_obs
+        self.obs_buf = torch.zeros((self.N, self.num_obs)); self.states_buf = torch.zeros((self.N, 93)); self.rew_buf = torch.zeros(self.N)
+        self.extras_buf = torch.zeros(10); self.terms = torch.zeros((11, self.N)); self.stats_i64 = torch.zeros(6, dtype=torch.int64)
         self._sr = [0.0, 0.0, 0.0]
         self._sync_out()
 
@@ -62,7 +63,7 @@ class OracleEngine:
         self._sync_in()
         a = np.clip(actions.detach().cpu().numpy().astype(np.float64), -self.clip_actions, self.clip_actions)
         gr = None if goal_rand is None else goal_rand.detach().cpu().numpy().astype(np.float64)
-        obs = np.zeros((self.N, 64)); states = np.zeros((self.N, 93)); rew = np.zeros(self.N); terms = np.zeros((self.N, 8))
+        obs = np.zeros((self.N, self.num_obs)); states = np.zeros((self.N, 93)); rew = np.zeros(self.N); terms = np.zeros((self.N, 11))
         for o, sl in self._halves():
             ph, tk, ct = self.phys[sl].copy(), self.task[sl].copy(), self.cntv[sl].copy()
             # env ids feed the hash RNG: the oracle numbers envs from 0 inside each call, so sample goals here for parity
@@ -94,10 +95,10 @@ class OracleEngine:
     def post_physics(self, actions, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
         self._sync_in()
         a = np.clip(actions.detach().cpu().numpy().astype(np.float64), -self.clip_actions, self.clip_actions)
-        obs = np.zeros((self.N, 64)); states = np.zeros((self.N, 93)); rew = np.zeros(self.N); terms = np.zeros((self.N, 8))
+        obs = np.zeros((self.N, self.num_obs)); states = np.zeros((self.N, 93)); rew = np.zeros(self.N); terms = np.zeros((self.N, 11))
         for o, sl in self._halves():
             ph, tk, ct = self.phys[sl].copy(), self.task[sl].copy(), self.cntv[sl].copy()
-            n = ph.shape[0]; rb = np.zeros((n, 87)); mode = o._ep.mode
+            n = ph.shape[0]; rb = np.zeros((n, 99)); mode = o._ep.mode
             rb[:, 0:12] = ph[:, 13:25]; rb[:, 12:24] = ph[:, 25:37]; rb[:, 24:36] = (ph[:, 25:37] - tk[:, 12:24]) / o._ep.ctrl_dt
             tk[:, 12:24] = ph[:, 25:37]
             rb[:, 36:49] = ph[:, 0:13] if mode == 0 else ph[:, 37:50]

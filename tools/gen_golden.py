@@ -33,7 +33,14 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 # ----------------------------------------------------------------------------- placeholders
-class _Inert:
+class _InertMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: None
+
+
+class _Inert(metaclass=_InertMeta):
     def __init__(self, *a, **k):
         pass
 
@@ -135,6 +142,8 @@ class FakeRobot:
         self.tip_positions, self.knee_positions = z(N, 4, 3), z(N, 8, 3)
 
     def __getattr__(self, name):          # every setter / updater is a no-op
+        if name == "_robot_articulation":
+            return _Inert()
         return lambda *a, **k: None
 
 
@@ -164,7 +173,14 @@ def _rand_unit_quat(g, n, small=None):
 
 
 def make_task(kind, N):
-    if kind == "loco":
+    cc = kind.endswith("_cc")
+    if kind == "loco_cc":
+        from tasks.quadruped_pose_control_tasks.quadruped_pose_control_custom_controller import QuadrupedPoseControlCustomController as T
+        mangle = "_QuadrupedPoseControlCustomController"
+    elif kind == "mani_cc":
+        from tasks.quadruped_manipulate_plate.quadruped_manipulate_plate_custom_controller import QuadrupedManipulatePlateCustomController as T
+        mangle = "_QuadrupedManipulatePlateCustomController"
+    elif kind == "loco":
         from tasks.quadruped_pose_control_tasks.quadruped_pose_control import QuadrupedPoseControl as T
         mangle = "_QuadrupedPoseControl"
     else:
@@ -173,11 +189,12 @@ def make_task(kind, N):
     from utils.math import transform_vectors
     t = object.__new__(T)
     dev = "cpu"
-    t._device, t._num_envs, t._num_actions, t._num_observations, t._num_states = dev, N, 12, 64, 93
-    t._max_episode_length = 300
+    t._device, t._num_envs, t._num_actions, t._num_observations, t._num_states = dev, N, 12, (88 if cc else 64), 93
+    t._max_episode_length = 500 if cc else 300
+    t._env = types.SimpleNamespace(_world=None)
     t._dr_randomizer = FakeDR()
     z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
-    t.obs_buf, t.states_buf, t.rew_buf = z(N, 64), z(N, 93), z(N)
+    t.obs_buf, t.states_buf, t.rew_buf = z(N, 88 if cc else 64), z(N, 93), z(N)
     t.reset_buf = torch.ones(N, dtype=torch.long); t.progress_buf = z(N, dt=torch.long); t.extras = {}
     t.last_actions, t.current_actions = z(N, 12), z(N, 12)
     t.last_base_tip_positions = z(N, 4, 3)
@@ -194,11 +211,23 @@ def make_task(kind, N):
     t.success_rate = torch.tensor(0.0)
     t.randomization_buf = z(N, dt=torch.long)
     init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4)
-    if kind == "loco":
+    if cc:   # class-default pose (robot/quadruped_robot.py:45-52); custom-controller state (…_custom_controller.py:175-195)
+        init_q = torch.tensor([-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92] + [0.953, -0.953] * 4)
+        t.current_joint_position_targets = init_q[:12].repeat(N, 1).clone()
+        t.last_joint_position_targets = t.current_joint_position_targets.clone()
+        t.current_joint_position_targets_se = torch.tensor([-1.2, 1.2, 1.2, -1.2, -1.57, 0.7, 1.57, 0.7, 1.57, 0.7, -1.57, 0.7]).repeat(N, 1)
+        t.joint_position_target_se_upper = torch.tensor(T.max_joint_pos_swing_ext, dtype=torch.float32)
+        t.joint_position_target_se_lower = torch.tensor(T.min_joint_pos_swing_ext, dtype=torch.float32)
+        t.last_rot_dist = torch.zeros(N)
+        if kind == "loco_cc":
+            t.joint_positions_loco = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_loco = torch.zeros(N, 12)
+        else:
+            t.joint_positions_mani = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_mani = torch.zeros(N, 12)
+    if kind in ("loco", "loco_cc"):
         t.robot_locomotion = FakeRobot(N)
         t.pose_indicator_loco = FakeObj(N)
         t.default_joint_positions_loco = init_q.repeat((N, 1))
-        t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.14]).repeat((N, 1))
+        t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.18 if cc else 0.14]).repeat((N, 1))
         t.default_robot_quaternions_loco = torch.tensor([1.0, 0, 0, 0]).repeat((N, 1))
         t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
     else:
@@ -207,7 +236,7 @@ def make_task(kind, N):
         t.default_joint_positions_mani = init_q.repeat((N, 1))
         t.default_robot_positions_mani = torch.tensor([0.0, 0.0, 0.0]).repeat((N, 1))
         t.default_robot_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
-        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.14]).repeat((N, 1))
+        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.18 if cc else 0.14]).repeat((N, 1))
         t.default_obj_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
         t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
         setattr(t, mangle + "__corner_pos_world",
@@ -221,11 +250,13 @@ def gen_task(kind, N=32, T=26, seed=7):
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
     t = make_task(kind, N)
-    robot = t.robot_locomotion if kind == "loco" else t.robot_manipulation
-    init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
+    cc = kind.endswith("_cc"); base_kind = kind[:4]
+    robot = t.robot_locomotion if base_kind == "loco" else t.robot_manipulation
+    init_q = torch.tensor([-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]) if cc else \
+        torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
     rec = {k: [] for k in ("readback", "actions", "goal_rand", "obs", "states", "rew", "reset_buf", "goal_reset_buf",
                            "successes", "consecutive_successes", "progress_buf", "last_actions", "last_base_tip",
-                           "goal_quaternions", "extras", "success_rate", "num_successes", "num_resets", "joint_reset")}
+                           "goal_quaternions", "extras", "success_rate", "num_successes", "num_resets", "joint_reset", "torque", "se", "last_targets", "last_rot_dist")}
     extras_keys = None
     for step in range(T):
         actions = (torch.rand(N, 12, generator=g) * 2 - 1).clamp(-1, 1)
@@ -236,6 +267,8 @@ def gen_task(kind, N=32, T=26, seed=7):
             st = torch.get_rng_state()
             goal_rand[ids] = torch.rand((len(ids), 3))
             torch.set_rng_state(st)
+        if cc and step > 0:
+            pass
         t.pre_physics_step(actions)
         # ---- synthetic read-back state, spread across the thresholds of Appendix D
         q = init_q.repeat(N, 1) + 0.25 * torch.randn(N, 12, generator=g)
@@ -252,7 +285,7 @@ def gen_task(kind, N=32, T=26, seed=7):
         tips = 0.15 * torch.randn(N, 4, 3, generator=g)
         knees = torch.cat((0.15 * torch.randn(N, 8, 2, generator=g), 0.10 + 0.03 * torch.randn(N, 8, 1, generator=g)), dim=-1)
         knees[15, 3, 2] = 0.0399; knees[16, 3, 2] = 0.0401
-        if kind == "mani":
+        if base_kind == "mani":
             # plate near its rest pose above the inverted robot: world z ~ 0.13, flipped about x
             flip = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(N, 1)
             quat = quat_mul(_rand_unit_quat(g, N, small=0.2), flip)
@@ -264,17 +297,17 @@ def gen_task(kind, N=32, T=26, seed=7):
         track = torch.arange(20, 28)
         goal = t.goal_quaternions[track]
         small = _rand_unit_quat(g, len(track), small=0.02)
-        if kind == "loco":
+        if base_kind == "loco":
             quat[track] = quat_conjugate(quat_mul(small, goal))         # conj(bq) (x) conj(goal) ~ identity
         else:
             flip = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(len(track), 1)
             quat[track] = quat_mul(flip, quat_mul(small, goal))         # conj(q_r) (x) pq = small (x) goal
         quat = quat / quat.norm(dim=-1, keepdim=True)
         pos[track] = torch.tensor([0.0, 0.0, 0.13]); q[track] = init_q
-        knees[track, :, 2] = 0.1 if kind == "loco" else 0.02
+        knees[track, :, 2] = 0.1 if base_kind == "loco" else 0.02
         robot.joint_positions, robot.joint_velocities, robot.joint_accelerations = q, qd, acc
         robot.tip_positions, robot.knee_positions = tips, knees
-        if kind == "loco":
+        if base_kind == "loco":
             robot.base_positions, robot.base_quaternions = pos, quat
             robot.base_linear_velocities, robot.base_angular_velocities = lin, ang
         else:
@@ -283,6 +316,10 @@ def gen_task(kind, N=32, T=26, seed=7):
         t.progress_buf[:] += 1
         t.get_observations(); t.calculate_metrics(); t.is_done()
         rb = torch.cat((q, qd, acc, pos, quat, lin, ang, tips.reshape(N, 12), knees.reshape(N, 24), torch.zeros(N, 2)), dim=-1)
+        if cc:
+            rb = torch.cat((rb, t.torque), dim=-1)
+            rec["torque"].append(t.torque.clone()); rec["se"].append(t.current_joint_position_targets_se.clone())
+            rec["last_targets"].append(t.last_joint_position_targets.clone()); rec["last_rot_dist"].append(t.last_rot_dist.clone())
         if extras_keys is None:
             extras_keys = sorted(t.extras.keys())
         rec["readback"].append(rb); rec["actions"].append(actions); rec["goal_rand"].append(goal_rand)
@@ -296,7 +333,7 @@ def gen_task(kind, N=32, T=26, seed=7):
         rec["success_rate"].append(torch.as_tensor(t.success_rate, dtype=torch.float32).clone())
         rec["num_successes"].append(t.num_successes.clone()); rec["num_resets"].append(t.num_resets.clone())
         rec["joint_reset"].append((t.joint1_pos_reset + t.joint23_pos_reset).clone())
-    out = {k: torch.stack(v).numpy() for k, v in rec.items()}
+    out = {k: torch.stack(v).numpy() for k, v in rec.items() if len(v) > 0}
     out["extras_keys"] = np.array(extras_keys)
     return out
 
@@ -389,8 +426,8 @@ def main():
     _install_placeholders()
     sys.path[:0] = [REF_RL, os.path.dirname(REF_RL)]
     os.makedirs(OUT, exist_ok=True)
-    for kind in ("loco", "mani"):
-        d = gen_task(kind)
+    for kind in ("loco", "mani", "loco_cc", "mani_cc"):
+        d = gen_task(kind, T=32 if kind.endswith("_cc") else 26)
         np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
         print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "states", "rew", "extras")},
               "resets/step", d["reset_buf"].sum(1)[:8], "max consec", d["consecutive_successes"].max(),
