@@ -79,7 +79,7 @@ def main():
     pool = [torch.rand(N, 12, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
     out_obs = [torch.empty(N, 64, device=dev) for _ in range(2)]
     out_states = [torch.empty(N, 93, device=dev) for _ in range(2)]
-    out_extras = torch.empty(10, device=dev)
+    out_extras = torch.empty(13, device=dev)
     roll_rew = torch.zeros(ROLLOUT, N, device=dev)           # the kernel writes rewards / dones straight into the rollout slots
     roll_done = torch.zeros(ROLLOUT, N, dtype=torch.int64, device=dev)
     payload = torch.zeros(2, ROLLOUT, N, device=dev)

@@ -31,12 +31,15 @@ extern "C" {
 #define LM_MODE_LOCO 0   /* free base on a ground plane   (QuadrupedPoseControl)      */
 #define LM_MODE_MANI 1   /* fixed inverted base + plate    (QuadrupedManipulatePlate)  */
 
-#define LM_STATE_ROWS 90   /* float state, SoA [row][N]: see DESIGN.md 4.1 */
+#define LM_STATE_ROWS 115  /* float state, SoA [row][N]: see DESIGN.md 4.1 */
 #define LM_CNT_ROWS 6      /* int64 counters, SoA [row][N] */
-#define LM_NUM_OBS 64
+#define LM_NUM_OBS 64        /* velocity-drive tasks; the custom-controller tasks have 88 (lm_num_obs) */
+#define LM_MAX_OBS 88
+#define LM_TERM_ROWS 11
 #define LM_NUM_STATES 93
 #define LM_NUM_ACTIONS 12
-#define LM_NUM_EXTRAS 10  /* 7 reward-term means, success_rate, success_rate of task 0 / task 1 (co-train) */
+#define LM_NUM_EXTRAS 13  /* 7 reward-term means, success_rate, success_rate of task 0 / task 1 (co-train),
+                             custom-controller means: mechanical_power, position_target_error, rot_dist_decreasing */
 #define LM_TABLE_FLOATS 486  /* 10 hub + 4 x 119 limb (RobotModel.packed_table) */
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
@@ -55,6 +58,13 @@ typedef struct lm_params {
   float h_base, h_corner, h_knee, corner[4][3];
   float clip_obs, clip_actions;
   int32_t max_reset_counts;
+  /* custom-controller task family (quadruped_pose_control_custom_controller.py:24-52,88-97,255-307) */
+  int32_t variant;           /* 0 velocity-drive tasks, 1 custom-controller tasks */
+  int32_t num_obs;           /* 64 / 88 */
+  float pd_kp, joint_damping, act_scale_se;
+  float se_lo[12], se_hi[12], init_se[12];
+  float torque_div, power_scale, target_err_scale, rot_dec_scale, rot_dec_thresh;
+  int32_t cc_update_last_tgt;
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */
@@ -68,12 +78,12 @@ typedef enum {
   LM_PTR_STATE = 0,     /* float [LM_STATE_ROWS][N]                                  */
   LM_PTR_CNT = 1,       /* int64 [LM_CNT_ROWS][N]: successes, consecutive_successes,
                            goal_reset_buf, reset_buf, progress_buf, episode_count    */
-  LM_PTR_OBS_BUF = 2,   /* float [N][64]  task.obs_buf (unclipped)   rl_task.py:107  */
+  LM_PTR_OBS_BUF = 2,   /* float [N][lm_num_obs()]  task.obs_buf (unclipped)   rl_task.py:107  */
   LM_PTR_STATES_BUF = 3,/* float [N][93]  task.states_buf                            */
   LM_PTR_REW_BUF = 4,   /* float [N]      task.rew_buf                               */
-  LM_PTR_EXTRAS = 5,    /* float [10]     reward-term means + success rates           */
+  LM_PTR_EXTRAS = 5,    /* float [LM_NUM_EXTRAS]  reward-term means + success rates     */
   LM_PTR_STATS = 6,     /* int64 [6] {num_successes, num_resets} x {all, task 0, task 1}; float [3] rates at byte 48 */
-  LM_PTR_TERMS = 7      /* float [8][N]   per-env reward terms of the last step      */
+  LM_PTR_TERMS = 7      /* float [LM_TERM_ROWS][N]  per-env reward terms of the last step */
 } lm_ptr_kind;
 
 /* Create an engine for n_envs environments on the current HIP device.
@@ -92,7 +102,7 @@ int lm_destroy(lm_engine* h);
  *   actions     device float [N][12]
  *   goal_rand   device float [N][3] uniforms for goal sampling, or NULL for the in-kernel hash RNG
  *   out_*       device buffers receiving clipped copies for the caller (any may be NULL):
- *               obs [N][64], states [N][93], rew [N], resets int64 [N], extras float [LM_NUM_EXTRAS]
+ *               obs [N][lm_num_obs], states [N][93], rew [N], resets int64 [N], extras float [LM_NUM_EXTRAS]
  *   stream      hipStream_t (void* here so the header needs no HIP include) */
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states,
             float* out_rew, int64_t* out_resets, float* out_extras, void* stream);
@@ -108,7 +118,7 @@ int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* o
 /* RLTask.reset(): flag every env for reset (rl_task.py:227-230). */
 int lm_reset_all(lm_engine* h, void* stream);
 
-/* Task layer alone on explicit read-back inputs (device float [N][87], layout of oracle LMO_READBACK);
+/* Task layer alone on explicit read-back inputs (device float [N][99], layout of oracle LMO_READBACK);
  * uses and updates the handle's task state / counters exactly like the tail of lm_step.
  * Test entry point for the golden vectors captured from the reference's Python. */
 int lm_task_eval(lm_engine* h, const float* readback, const float* actions, float* out_obs, float* out_states,
@@ -128,6 +138,7 @@ int lm_debug_dynamics(lm_engine* h, float* M, float* hvec, void* stream);
 
 void* lm_ptr(lm_engine* h, int kind);
 int lm_num_envs(const lm_engine* h);
+int lm_num_obs(const lm_engine* h);      /* observation width of this engine (64 or 88) */
 int lm_set_seed(lm_engine* h, uint32_t seed);
 const char* lm_last_error(void);
 const char* lm_version(void);

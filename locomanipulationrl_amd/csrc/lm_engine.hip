@@ -21,7 +21,7 @@
 #define HUB_FLOATS 10
 #define LIMB_STRIDE 119
 #define ENVS_PER_WAVE 16
-#define NPART 12           // per-block partial sums: 7 reward terms, goal_reset, reset, pad
+#define NPART 12           // per-block partial sums: 7 reward terms, goal_reset, reset, 3 custom-controller terms
 
 // state rows
 #define R_FB0 0            // base: pos 0..2 quat 3..6 lin 7..9 ang 10..12
@@ -32,6 +32,9 @@
 #define R_LQD 62
 #define R_LTIP 74
 #define R_GOAL 86
+#define R_SE 90           // swing/extension position targets (custom-controller tasks)
+#define R_LTGT 102        // last joint position targets
+#define R_LRD 114         // last rot_dist
 
 #define SQRT2F 1.41421356237f
 
@@ -40,7 +43,7 @@ static int fail(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s"
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", #x, hipGetErrorString(e_)); return LM_EHIP; } } while (0)
 
 struct lm_engine {
-  int N, n_tasks, split, nblocks;
+  int N, n_tasks, split, nblocks, num_obs;
   uint32_t seed;
   lm_params* d_params;     // [2]
   float* d_table;
@@ -292,8 +295,8 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
 // robot base is fixed at (Rb, pb).
 template <int MODE>
 LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb, const Stash& St,
-                    FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3]) {
-  const float dt = P->dt, kd = P->kd, tmax = P->tau_max;
+                    FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3], float tau_acc[3]) {
+  const float dt = P->dt, kd = P->kd, tmax = P->tau_max, cj = P->joint_damping;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
   float bn;
   {
@@ -372,8 +375,8 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     const int di[3] = {0, 3, 5};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      if (!sat[a]) { Ha[di[a]] += dt * kd; r[a] = kd * (tgt[a] - qd[a]) - hq[a]; }
-      else r[a] = tsat[a] - hq[a];
+      if (!sat[a]) { Ha[di[a]] += dt * (kd + cj); r[a] = kd * (tgt[a] - qd[a]) - cj * qd[a] - hq[a]; }
+      else { Ha[di[a]] += dt * cj; r[a] = tsat[a] - cj * qd[a] - hq[a]; }      // viscous joint damping is implicit in both cases
     }
     float Hi[6]; inv3sym(Ha, Hi);
     // K = Fq Hinv  (columns)
@@ -463,6 +466,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) {      // driven joints are speed-limited like PhysX's maxJointVelocity (config_module_joints.py:11,61-69)
+    tau_acc[a] += sat[a] ? tsat[a] : kd * (tgt[a] - qdn[a]);      // drive torque applied over this sub-step
     float v = fminf(fmaxf(qdn[a], -P->max_joint_vel), P->max_joint_vel);
     qd[a] = v; q[a] = fmaf(dt, v, q[a]);
   }
@@ -476,11 +480,12 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
 // ------------------------------------------------------------------------------------------------
 struct TaskIn {
   float q[3], qd[3], acc[3], act[3];       // this limb's joints (dof1, dof2, dof3)
+  float torque[3], tgtq[3];                // custom-controller tasks: logged torque, current joint position targets
   V3 tipw, knee2, knee3;                   // world positions of this limb's tip and knees
   V3 fp; Q4 fq; V3 lin, ang;               // free body (base or plate) world pose / velocity
 };
-struct TaskState { float lact[3]; V3 ltip; Q4 goal; int succ, consec, greset, reset, progress; };
-struct TaskOut { float rew; float terms[8]; };
+struct TaskState { float lact[3]; V3 ltip; Q4 goal; int succ, consec, greset, reset, progress; float ltgt[3]; float lrd; };
+struct TaskOut { float rew; float terms[11]; };
 
 template <int MODE>
 LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const TaskIn& I, TaskState& S, TaskOut& O,
@@ -500,12 +505,13 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   }
   V3 btip = mulT(Rr, I.tipw - pr);
   Q4 qd_ = qmul(oq, qconj(S.goal));
-  float fl = (qd_.w < 0.f) ? -1.f : 1.f;
+  const bool var1 = (P->variant == 1); const int NO = P->num_obs;
+  float fl = (qd_.w < 0.f && !var1) ? -1.f : 1.f;        // the custom-controller tasks do not flip the sign (…custom_controller.py:429-431)
   Q4 qf; qf.w = fl * qd_.w; qf.x = fl * qd_.x; qf.y = fl * qd_.y; qf.z = fl * qd_.z;
   M3 Ro = quat_to_mat(oq.w, oq.x, oq.y, oq.z);
   V3 up = Ro.c2;
   const int j1 = limb, j2 = 4 + 2 * limb, j3 = 5 + 2 * limb;
-  float* ob = sObs + envl * 64; float* st = sSt + envl * 93;
+  float* ob = sObs + envl * NO; float* st = sSt + envl * 93;
   if (limb == 0) {
     ob[0] = P->s_pos * opos.x; ob[1] = P->s_pos * opos.y; ob[2] = P->s_pos * opos.z;
     ob[3] = up.x; ob[4] = up.y; ob[5] = up.z;
@@ -525,6 +531,7 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
     int j = jj[a];
     ob[16 + j] = P->s_q * I.q[a]; ob[28 + j] = P->s_qd * I.qd[a]; ob[40 + j] = I.act[a]; ob[52 + j] = S.lact[a];
     st[13 + j] = P->s_q * I.q[a]; st[25 + j] = P->s_qd * I.qd[a]; st[69 + j] = I.act[a]; st[81 + j] = S.lact[a];
+    if (var1) { ob[64 + j] = 0.3f * I.tgtq[a]; ob[76 + j] = 0.3f * S.ltgt[a]; }      // :432-455
   }
   st[45 + 3 * limb] = btip.x; st[46 + 3 * limb] = btip.y; st[47 + 3 * limb] = btip.z;
   st[57 + 3 * limb] = S.ltip.x; st[58 + 3 * limb] = S.ltip.y; st[59 + 3 * limb] = S.ltip.z;
@@ -535,7 +542,15 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   float rot_rew = P->quat_scale / (fabsf(rot_dist) + P->rot_eps);
   float trans = sqrtf(opos.x * opos.x + opos.y * opos.y) * P->trans_scale;
   float accp = quad_sum(fabsf(I.acc[0]) * P->acc_scale + fabsf(I.acc[1]) * P->acc_scale + fabsf(I.acc[2]) * P->acc_scale);
-  float rate = quad_sum(fabsf(S.lact[0] - I.act[0]) + fabsf(S.lact[1] - I.act[1]) + fabsf(S.lact[2] - I.act[2])) * P->rate_scale;
+  float rate = quad_sum(var1 ? (fabsf(I.act[0]) + fabsf(I.act[1]) + fabsf(I.act[2]))
+                             : (fabsf(S.lact[0] - I.act[0]) + fabsf(S.lact[1] - I.act[1]) + fabsf(S.lact[2] - I.act[2]))) * P->rate_scale;
+  float powp = 0.f, terr = 0.f, rdec = 0.f;
+  if (var1) {      // mechanical power, position-target error, rot-dist-decreasing terms (:530-545)
+    powp = quad_sum(fabsf(I.torque[0] * I.qd[0]) + fabsf(I.torque[1] * I.qd[1]) + fabsf(I.torque[2] * I.qd[2])) * P->power_scale;
+    terr = quad_sum(fabsf(S.ltgt[0] - I.q[0]) + fabsf(S.ltgt[1] - I.q[1]) + fabsf(S.ltgt[2] - I.q[2])) * P->target_err_scale;
+    rdec = ((rot_dist > P->rot_dec_thresh) ? 1.f : 0.f) * (S.lrd - rot_dist) * P->rot_dec_scale;
+    S.lrd = rot_dist;
+  }
   int cgr = (S.consec > P->max_consec) ? 1 : 0;
   float bonus = P->bonus * (float)cgr;
   int succ = (fabsf(rot_dist) <= P->succ_thresh) ? 1 : 0;
@@ -544,7 +559,7 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   int rst = ((dd < P->d23_rst[0]) || (dd > P->d23_rst[1])) + ((I.q[0] < P->d1_rst[limb][0]) || (I.q[0] > P->d1_rst[limb][1]));
   brk = quad_sum_i(brk); rst = quad_sum_i(rst);
   float limp = (brk > 0) ? P->limit_pen : 0.f;
-  float total = rot_rew + trans + accp + rate + bonus + limp;
+  float total = rot_rew + trans + accp + rate + bonus + limp + powp + terr + rdec;
   S.greset = cgr;
   int both = (succ && S.succ) ? 1 : 0;
   int consec = both ? (S.consec + 1) : 0;
@@ -573,6 +588,8 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   S.reset = reset;
   O.rew = total;
   O.terms[0] = rot_rew; O.terms[1] = trans; O.terms[2] = accp; O.terms[3] = rate; O.terms[4] = bonus; O.terms[5] = limp; O.terms[6] = fallp; O.terms[7] = (float)cgr;
+  O.terms[8] = powp; O.terms[9] = terr; O.terms[10] = rdec;
+  if (var1 && P->cc_update_last_tgt) { S.ltgt[0] = I.tgtq[0]; S.ltgt[1] = I.tgtq[1]; S.ltgt[2] = I.tgtq[2]; }      // :723-725
 }
 
 // shared tail: write staged obs / states, reward, counters, per-block partial sums
@@ -586,12 +603,13 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   __builtin_amdgcn_wave_barrier();
   const float clip = P->clip_obs;
   int nenv = min(ENVS_PER_WAVE, N - env0);
-  // obs: nenv*64 floats contiguous
-  for (int i = lane; i < nenv * 16; i += 64) {
+  const int NO = P->num_obs;
+  // obs: nenv*NO floats contiguous (NO = 64 or 88, both multiples of 4)
+  for (int i = lane; i < nenv * (NO / 4); i += 64) {
     float4 v = reinterpret_cast<const float4*>(sObs)[i];
-    reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * 64)[i] = v;
+    reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NO)[i] = v;
     if (W.out_obs) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
-      reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * 64)[i] = v; }
+      reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NO)[i] = v; }
   }
   for (int i = lane; i < nenv * 93; i += 64) {
     float v = sSt[i];
@@ -605,23 +623,25 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     cnt[0 * (size_t)N + env] = S.succ; cnt[1 * (size_t)N + env] = S.consec; cnt[2 * (size_t)N + env] = S.greset;
     cnt[3 * (size_t)N + env] = S.reset; cnt[4 * (size_t)N + env] = S.progress; cnt[5 * (size_t)N + env] = episode;
 #pragma unroll
-    for (int k = 0; k < 8; k++) W.terms[(size_t)k * N + env] = O.terms[k];
+    for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
   }
   // per-block partial sums (fixed order -> deterministic means)
-  float part[9];
+  float part[12];
   bool cnts = active && (limb == 0);
 #pragma unroll
   for (int k = 0; k < 8; k++) part[k] = cnts ? O.terms[k] : 0.f;
   part[8] = cnts ? (float)S.reset : 0.f;
 #pragma unroll
-  for (int k = 0; k < 9; k++) {
+  for (int k = 0; k < 3; k++) part[9 + k] = cnts ? O.terms[8 + k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
     float v = part[k];
     v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     part[k] = v;
   }
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) W.partials[(size_t)k * gridDim.x + blockIdx.x] = part[k];      // [k][block]: coalesced for k_finalize
+    for (int k = 0; k < 12; k++) W.partials[(size_t)k * gridDim.x + blockIdx.x] = part[k];      // [k][block]: coalesced for k_finalize
   }
 }
 
@@ -678,11 +698,31 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   }
   M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
-  // ---- take_action (robot.py:452-454): velocity targets
-  {
+  float tau_acc[3] = {0.f, 0.f, 0.f}, tgtq[3] = {0.f, 0.f, 0.f};
+  const bool var1 = (P->variant == 1);
+  const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
+  if (!var1) {
+    // ---- take_action (robot.py:452-454): velocity targets
     float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
-    const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
-    for (int s = 0; s < nsub; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt);
+    for (int s = 0; s < nsub; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+  } else {
+    // ---- custom-controller tasks (quadruped_pose_control_custom_controller.py:255-307): the action integrates the swing / extension
+    // position targets; the actuator torque  clamp(kp (q* - q) - kd qd, +-tau_max)  is re-evaluated every sub-step.  It is the same drive
+    // as above with damping gain kd and the position-derived velocity target  v* = kp / kd (q* - q)  (implicit in qd, 2-pass clamp).
+    float se[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float v = do_reset ? P->init_se[jj[a]] : st[(size_t)(R_SE + jj[a]) * N + env];
+      if (!A.skip_reset || A.nsub != 0) v = fminf(fmaxf(v + act[a] * P->act_scale_se, P->se_lo[jj[a]]), P->se_hi[jj[a]]);
+      se[a] = v;
+      if (active) st[(size_t)(R_SE + jj[a]) * N + env] = v;
+    }
+    tgtq[0] = se[0]; tgtq[1] = se[1] + 0.5f * se[2]; tgtq[2] = se[1] - 0.5f * se[2];      // dof1, dof2 = swing + ext/2, dof3 = swing - ext/2
+    const float g = P->pd_kp / P->kd;
+    for (int s = 0; s < nsub; s++) {
+      float tgt[3] = {g * (tgtq[0] - q[0]), g * (tgtq[1] - q[1]), g * (tgtq[2] - q[2])};
+      substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+    }
   }
   // ---- task-layer state
   TaskState S; int episode; float lqd[3];
@@ -692,6 +732,12 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   for (int a = 0; a < 3; a++) { S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env]; lqd[a] = st[(size_t)(R_LQD + jj[a]) * N + env]; }
   S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
   S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
+  S.lrd = 0.f; S.ltgt[0] = S.ltgt[1] = S.ltgt[2] = 0.f;
+  if (var1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) S.ltgt[a] = st[(size_t)(R_LTGT + jj[a]) * N + env];
+    S.lrd = st[(size_t)R_LRD * N + env];
+  }
   if (do_reset) {
     float u3[3];
     if (A.goal_rand) { u3[0] = A.goal_rand[(size_t)env * 3]; u3[1] = A.goal_rand[(size_t)env * 3 + 1]; u3[2] = A.goal_rand[(size_t)env * 3 + 2]; }
@@ -702,6 +748,14 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     for (int a = 0; a < 3; a++) { S.lact[a] = 0.f; lqd[a] = 0.f; }
     S.ltip = v3(P->default_tip[3 * limb], P->default_tip[3 * limb + 1], P->default_tip[3 * limb + 2]);
     S.succ = 0; S.consec = 0; S.greset = 0; S.reset = 0; S.progress = 0; episode += 1;
+    if (var1) {      // :371-384
+#pragma unroll
+      for (int a = 0; a < 3; a++) S.ltgt[a] = P->init_q[jj[a]];
+      Q4 qb; qb.w = (MODE == 0) ? P->init_base_quat[0] : 1.f; qb.x = (MODE == 0) ? -P->init_base_quat[1] : 0.f;
+      qb.y = (MODE == 0) ? -P->init_base_quat[2] : 0.f; qb.z = (MODE == 0) ? -P->init_base_quat[3] : 0.f;
+      Q4 d4 = qmul(qb, qconj(S.goal));
+      S.lrd = 2.0f * asinf(fminf(sqrtf(d4.x * d4.x + d4.y * d4.y + d4.z * d4.z), 1.0f));
+    }
   }
   // ---- blow-up guard: the reference only prints NaNs and asserts (quadruped_pose_control.py:550-558); here a non-finite or
   // exploding state is replaced by the reset pose and the env is flagged for reset, so one bad env cannot poison a batch
@@ -731,7 +785,8 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     I.tipw = pb + mul(Rb, x); I.knee2 = pb + mul(Rb, K.o2); I.knee3 = pb + mul(Rb, K.o3);
   }
 #pragma unroll
-  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a]; }
+  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a];
+    I.torque[a] = var1 ? tau_acc[a] / P->torque_div : 0.f; I.tgtq[a] = tgtq[a]; }      // logged torque = sum over sub-steps / control_decimal (:307)
   TaskOut O;
   task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
   if (blown) S.reset = 1;
@@ -743,6 +798,11 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
       st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a]; st[(size_t)(R_LQD + jj[a]) * N + env] = qd[a];
     }
     st[(size_t)(R_LTIP + 3 * limb) * N + env] = S.ltip.x; st[(size_t)(R_LTIP + 3 * limb + 1) * N + env] = S.ltip.y; st[(size_t)(R_LTIP + 3 * limb + 2) * N + env] = S.ltip.z;
+    if (var1) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) st[(size_t)(R_LTGT + jj[a]) * N + env] = S.ltgt[a];
+      if (limb == 0) st[(size_t)R_LRD * N + env] = S.lrd;
+    }
     if (limb == 0) {
       st[(size_t)(fb + 0) * N + env] = F.p.x; st[(size_t)(fb + 1) * N + env] = F.p.y; st[(size_t)(fb + 2) * N + env] = F.p.z;
       st[(size_t)(fb + 3) * N + env] = F.q.w; st[(size_t)(fb + 4) * N + env] = F.q.x; st[(size_t)(fb + 5) * N + env] = F.q.y; st[(size_t)(fb + 6) * N + env] = F.q.z;
@@ -756,7 +816,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
 
 __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
-  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * 64];
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
   load_table(A.table, sTab, threadIdx.x);
@@ -778,27 +838,34 @@ __global__ void __launch_bounds__(256) k_finalize(const float* partials, int nbl
                                                   float* extras, float* out_extras) {
   __shared__ float red[4][16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  float s[11];
+  float s[14];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     float a = 0.f;
     for (int b = t; b < nblocks; b += 256) a += partials[(size_t)k * nblocks + b];
     s[k] = a;
   }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {          // custom-controller reward terms
+    float a = 0.f;
+    for (int b = t; b < nblocks; b += 256) a += partials[(size_t)(9 + k) * nblocks + b];
+    s[11 + k] = a;
+  }
   // first-task (locomotion half) share of the goal-reset / reset counts
   s[9] = 0.f; s[10] = 0.f;
   for (int b = t; b < split_block; b += 256) { s[9] += partials[(size_t)7 * nblocks + b]; s[10] += partials[(size_t)8 * nblocks + b]; }
 #pragma unroll
-  for (int k = 0; k < 11; k++) {
+  for (int k = 0; k < 14; k++) {
     float a = s[k];
     a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
     if (lane == 0) red[wv][k] = a;
   }
   __syncthreads();
-  if (t < 11) {
+  if (t < 14) {
     float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     red[0][t] = tot;
     if (t < 7) { float m = tot / (float)N; extras[t] = m; if (out_extras) out_extras[t] = m; }
+    if (t >= 11) { float m = tot / (float)N; extras[t - 1] = m; if (out_extras) out_extras[t - 1] = m; }     // extras 10..12
   }
   __syncthreads();
   if (t == 0) {
@@ -836,6 +903,7 @@ __global__ void __launch_bounds__(64) k_apply_resets(StepArgs A) {
     st[(size_t)(R_Q + jj[a]) * N + env] = P->init_q[jj[a]]; st[(size_t)(R_QD + jj[a]) * N + env] = 0.f;
     st[(size_t)(R_LACT + jj[a]) * N + env] = 0.f; st[(size_t)(R_LQD + jj[a]) * N + env] = 0.f;
     st[(size_t)(R_LTIP + 3 * limb + a) * N + env] = P->default_tip[3 * limb + a];
+    st[(size_t)(R_SE + jj[a]) * N + env] = P->init_se[jj[a]]; st[(size_t)(R_LTGT + jj[a]) * N + env] = P->init_q[jj[a]];
   }
   __builtin_amdgcn_wave_barrier();
   if (limb == 0) {
@@ -845,6 +913,10 @@ __global__ void __launch_bounds__(64) k_apply_resets(StepArgs A) {
     }
     for (int k = 0; k < 4; k++) { st[(size_t)(R_FB0 + 3 + k) * N + env] = P->init_base_quat[k]; st[(size_t)(R_FB1 + 3 + k) * N + env] = P->init_plate_quat[k]; }
     st[(size_t)(R_GOAL + 0) * N + env] = g.w; st[(size_t)(R_GOAL + 1) * N + env] = g.x; st[(size_t)(R_GOAL + 2) * N + env] = g.y; st[(size_t)(R_GOAL + 3) * N + env] = g.z;
+    const bool fixedb = (P->mode == LM_MODE_MANI);
+    Q4 qb; qb.w = fixedb ? 1.f : P->init_base_quat[0]; qb.x = fixedb ? 0.f : -P->init_base_quat[1]; qb.y = fixedb ? 0.f : -P->init_base_quat[2]; qb.z = fixedb ? 0.f : -P->init_base_quat[3];
+    Q4 d4 = qmul(qb, qconj(g));
+    st[(size_t)R_LRD * N + env] = 2.0f * asinf(fminf(sqrtf(d4.x * d4.x + d4.y * d4.y + d4.z * d4.z), 1.0f));
   }
 }
 __global__ void __launch_bounds__(64) k_apply_resets_cnt(int64_t* cnt, int N) {
@@ -886,7 +958,8 @@ LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sT
   for (int a = 0; a < 3; a++) tgt[a] = targets[(size_t)env * 12 + jj[a]];
   M3 Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
-  for (int s = 0; s < n; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt);
+  float tau_acc[3] = {0.f, 0.f, 0.f};
+  for (int s = 0; s < n; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
   if (active) store_phys<MODE>(A.state, N, env, limb, F, q, qd);
 }
 __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* targets, int n) {
@@ -954,10 +1027,19 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
   const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
   const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   float* st = A.state; int64_t* cnt = A.cnt;
-  const float* rb = rb_all + (size_t)env * 87;
+  const float* rb = rb_all + (size_t)env * 99;
   TaskIn I; TaskState S; TaskOut O;
   for (int a = 0; a < 3; a++) { I.q[a] = rb[jj[a]]; I.qd[a] = rb[12 + jj[a]]; I.acc[a] = rb[24 + jj[a]];
-    I.act[a] = clampf(A.actions[(size_t)env * 12 + jj[a]], P->clip_actions); S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env]; }
+    I.act[a] = clampf(A.actions[(size_t)env * 12 + jj[a]], P->clip_actions); S.lact[a] = st[(size_t)(R_LACT + jj[a]) * N + env];
+    I.torque[a] = rb[87 + jj[a]]; S.ltgt[a] = st[(size_t)(R_LTGT + jj[a]) * N + env]; }
+  {
+    // custom-controller tasks: integrate the swing / extension targets like pre_physics_step (:255-276)
+    float se[3];
+    for (int a = 0; a < 3; a++) { se[a] = st[(size_t)(R_SE + jj[a]) * N + env];
+      if (P->variant == 1) { se[a] = fminf(fmaxf(se[a] + I.act[a] * P->act_scale_se, P->se_lo[jj[a]]), P->se_hi[jj[a]]); if (active) st[(size_t)(R_SE + jj[a]) * N + env] = se[a]; } }
+    I.tgtq[0] = se[0]; I.tgtq[1] = se[1] + 0.5f * se[2]; I.tgtq[2] = se[1] - 0.5f * se[2];
+    S.lrd = st[(size_t)R_LRD * N + env];
+  }
   I.fp = v3(rb[36], rb[37], rb[38]); I.fq.w = rb[39]; I.fq.x = rb[40]; I.fq.y = rb[41]; I.fq.z = rb[42];
   I.lin = v3(rb[43], rb[44], rb[45]); I.ang = v3(rb[46], rb[47], rb[48]);
   I.tipw = v3(rb[49 + 3 * limb], rb[50 + 3 * limb], rb[51 + 3 * limb]);
@@ -968,13 +1050,14 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
   S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; int episode = (int)cnt[5 * (size_t)N + env];
   task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
   if (active) {
-    for (int a = 0; a < 3; a++) st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a];
+    for (int a = 0; a < 3; a++) { st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a]; st[(size_t)(R_LTGT + jj[a]) * N + env] = S.ltgt[a]; }
+    if (limb == 0) st[(size_t)R_LRD * N + env] = S.lrd;
     st[(size_t)(R_LTIP + 3 * limb) * N + env] = S.ltip.x; st[(size_t)(R_LTIP + 3 * limb + 1) * N + env] = S.ltip.y; st[(size_t)(R_LTIP + 3 * limb + 2) * N + env] = S.ltip.z;
   }
   write_outputs(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt);
 }
 __global__ void __launch_bounds__(64) k_task_eval(StepArgs A, const float* readback) {
-  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * 64];
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
   if (P->mode == LM_MODE_LOCO) task_only_body<0>(A, P, readback, sObs, sSt); else task_only_body<1>(A, P, readback, sObs, sSt);
@@ -1023,12 +1106,16 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     const lm_params& p = params[t];
     if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
       return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
+    if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || (p.variant != 0 && p.variant != 1) ||
+        (p.variant == 1) != (p.num_obs == LM_MAX_OBS) || (p.variant == 1 && !(p.kd > 0 && p.torque_div > 0)))
+      return fail(LM_EINVAL, "lm_create: invalid variant / num_obs (64 for velocity-drive tasks, 88 for custom-controller tasks, equal across tasks)");
   }
   lm_engine* h = new (std::nothrow) lm_engine();
   if (!h) return fail(LM_ENOMEM, "lm_create: host allocation failed");
   memset(h, 0, sizeof(*h));
   h->N = n_envs; h->n_tasks = n_tasks; h->split = (n_tasks == 2) ? split_env : n_envs; h->seed = seed;
   h->nblocks = (n_envs + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE;
+  h->num_obs = params[0].num_obs;
   h->h_params[0] = params[0]; h->h_params[1] = params[n_tasks - 1];
   derive_params(&h->h_params[0]); derive_params(&h->h_params[1]);
   size_t N = (size_t)n_envs;
@@ -1038,11 +1125,11 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_table, LM_TABLE_FLOATS * sizeof(float));
   ALLOC(h->d_state, LM_STATE_ROWS * N * sizeof(float));
   ALLOC(h->d_cnt, LM_CNT_ROWS * N * sizeof(int64_t));
-  ALLOC(h->d_obs, N * 64 * sizeof(float));
+  ALLOC(h->d_obs, N * (size_t)h->num_obs * sizeof(float));
   ALLOC(h->d_states, N * 93 * sizeof(float));
   ALLOC(h->d_rew, N * sizeof(float));
   ALLOC(h->d_extras, 16 * sizeof(float));
-  ALLOC(h->d_terms, 8 * N * sizeof(float));
+  ALLOC(h->d_terms, LM_TERM_ROWS * N * sizeof(float));
   ALLOC(h->d_partials, (size_t)h->nblocks * NPART * sizeof(float));
   ALLOC(h->d_stats, 64);
 #undef ALLOC
@@ -1169,6 +1256,7 @@ void* lm_ptr(lm_engine* h, int kind) {
   }
 }
 int lm_num_envs(const lm_engine* h) { return h ? h->N : 0; }
+int lm_num_obs(const lm_engine* h) { return h ? h->num_obs : 0; }
 int lm_set_seed(lm_engine* h, uint32_t seed) { if (!h) return fail(LM_EINVAL, "lm_set_seed: null handle"); h->seed = seed; return LM_OK; }
 
 }  // extern "C"

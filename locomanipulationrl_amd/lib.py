@@ -16,12 +16,12 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.environ.get("LM_ENGINE_SO", os.path.join(_CSRC, "liblm_engine.so"))     # override: kernel experiments only
 
-STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS = 90, 6, 64, 93, 12, 10, 486
+STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS, TERM_ROWS, READBACK = 115, 6, 64, 93, 12, 13, 486, 11, 99
 PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS = range(8)
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
-           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_set_seed", "lm_last_error", "lm_version",
+           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_num_obs", "lm_set_seed", "lm_last_error", "lm_version",
            "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward"]
 
 # rows of the SoA float state
@@ -50,6 +50,10 @@ class LmParams(C.Structure):
         ("h_base", C.c_float), ("h_corner", C.c_float), ("h_knee", C.c_float), ("corner", (C.c_float * 3) * 4),
         ("clip_obs", C.c_float), ("clip_actions", C.c_float),
         ("max_reset_counts", C.c_int32),
+        ("variant", C.c_int32), ("num_obs", C.c_int32), ("pd_kp", C.c_float), ("joint_damping", C.c_float), ("act_scale_se", C.c_float),
+        ("se_lo", C.c_float * 12), ("se_hi", C.c_float * 12), ("init_se", C.c_float * 12),
+        ("torque_div", C.c_float), ("power_scale", C.c_float), ("target_err_scale", C.c_float), ("rot_dec_scale", C.c_float),
+        ("rot_dec_thresh", C.c_float), ("cc_update_last_tgt", C.c_int32),
         ("plate_si", C.c_float * 10), ("plate_phi", C.c_float * 36), ("ctrl_dt_inv", C.c_float),
     ]
 
@@ -125,6 +129,7 @@ def load_library() -> C.CDLL:
     lib.lm_debug_dynamics.argtypes = [vp, fp, fp, vp]
     lib.lm_ptr.argtypes = [vp, ip]; lib.lm_ptr.restype = vp
     lib.lm_num_envs.argtypes = [vp]
+    lib.lm_num_obs.argtypes = [vp]
     lib.lm_set_seed.argtypes = [vp, C.c_uint32]
     lib.lm_gnn_forward.argtypes = [fp, ip, fp, fp, fp, vp]
     lib.lm_mlp_forward.argtypes = [fp, ip, fp, fp, fp, vp]
@@ -170,11 +175,12 @@ class Engine:
         N = self.num_envs
         self.state = self._wrap(PTR_STATE, (STATE_ROWS, N), "<f4")
         self.cnt = self._wrap(PTR_CNT, (CNT_ROWS, N), "<i8")
-        self.obs_buf = self._wrap(PTR_OBS_BUF, (N, NUM_OBS), "<f4")
+        self.num_obs = int(self.lib.lm_num_obs(self._h))
+        self.obs_buf = self._wrap(PTR_OBS_BUF, (N, self.num_obs), "<f4")
         self.states_buf = self._wrap(PTR_STATES_BUF, (N, NUM_STATES), "<f4")
         self.rew_buf = self._wrap(PTR_REW_BUF, (N,), "<f4")
         self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
-        self.terms = self._wrap(PTR_TERMS, (8, N), "<f4")
+        self.terms = self._wrap(PTR_TERMS, (TERM_ROWS, N), "<f4")
         self.stats_i64 = self._wrap(PTR_STATS, (6,), "<i8")
 
     # ------------------------------------------------------------------
@@ -206,7 +212,7 @@ class Engine:
         self._f32(actions, (N, NUM_ACTIONS))
         if goal_rand is not None:
             self._f32(goal_rand, (N, 3))
-        if out_obs is not None: self._f32(out_obs, (N, NUM_OBS))
+        if out_obs is not None: self._f32(out_obs, (N, self.num_obs))
         if out_states is not None: self._f32(out_states, (N, NUM_STATES))
         if out_rew is not None: self._f32(out_rew, (N,))
         if out_extras is not None: self._f32(out_extras, (NUM_EXTRAS,))
@@ -222,7 +228,7 @@ class Engine:
 
     def task_eval(self, readback, actions, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
         N = self.num_envs
-        self._f32(readback, (N, 87)); self._f32(actions, (N, NUM_ACTIONS))
+        self._f32(readback, (N, READBACK)); self._f32(actions, (N, NUM_ACTIONS))
         self._check(self.lib.lm_task_eval(self._h, self._p(readback), self._p(actions), self._p(out_obs), self._p(out_states),
                                           self._p(out_rew), self._p(out_resets), self._p(out_extras), self._stream()))
 
@@ -278,10 +284,10 @@ class Engine:
 
     def set_task_env_major(self, task):
         t = self.torch.as_tensor(np.ascontiguousarray(task, dtype=np.float32).T.copy(), device=self.device)
-        self.state[50:90].copy_(t)
+        self.state[50:50 + t.shape[0]].copy_(t)
 
     def get_task_env_major(self):
-        return self.state[50:90].T.contiguous().cpu().numpy()
+        return self.state[50:115].T.contiguous().cpu().numpy()
 
     def set_cnt_env_major(self, cnt):
         self.cnt.copy_(self.torch.as_tensor(np.ascontiguousarray(cnt, dtype=np.int64).T.copy(), device=self.device))

@@ -21,6 +21,8 @@ EXTRAS_KEYS = ["env/rewards/orientation_rew", "env/rewards/translation_penalty",
                "env/rewards/action_rate_penalty", "env/rewards/consecutive_successes_rew", "env/rewards/joint_limit_panelty",
                "env/rewards/fall_penalty", "env/success_rate"]     # ("panelty": sic, quadruped_pose_control.py:526)
 COTRAIN_EXTRAS_KEYS = ["env/success_rate_loco", "env/success_rate_mani"]                     # joint_locomanipulation.py:857-859
+CC_EXTRAS_KEYS = ["env/rewards/mechanical_power_penalty", "env/rewards/position_target_error_penalty",
+                  "env/rewards/rot_dist_decreasing_reward"]                                      # …custom_controller.py:629-631
 
 
 class _InertRandomizer:
@@ -141,14 +143,16 @@ class RLTask:
 
     def _alloc_outputs(self):
         N, dev = self._num_envs, self._device
-        return (torch.empty((N, 64), device=dev), torch.empty((N, 93), device=dev), torch.empty((N,), device=dev),
-                torch.empty((N,), dtype=torch.int64, device=dev), torch.empty((10,), device=dev))
+        return (torch.empty((N, self.num_observations), device=dev), torch.empty((N, 93), device=dev), torch.empty((N,), device=dev),
+                torch.empty((N,), dtype=torch.int64, device=dev), torch.empty((13,), device=dev))
 
     def _publish(self, out):
         obs, states, rew, resets, extras = out
         self.extras = {k: extras[i] for i, k in enumerate(EXTRAS_KEYS)}
         if self.split_env() is not None:
             self.extras.update({k: extras[8 + i] for i, k in enumerate(COTRAIN_EXTRAS_KEYS)})
+        if getattr(self, "custom_controller", False):
+            self.extras.update({k: extras[10 + i] for i, k in enumerate(self.cc_extras_keys)})
         if self.num_states == self.num_observations:
             states = obs
         return obs, states, rew, resets, self.extras
@@ -164,6 +168,9 @@ class RLTask:
 
     # staged form (scripts/random_policy.py:57-61)
     def pre_physics_step(self, actions: torch.Tensor) -> None:
+        if getattr(self, "custom_controller", False):
+            raise NotImplementedError("the custom-controller tasks run their physics inside pre_physics_step in the reference "
+                                      "(…custom_controller.py:285-296); use env.step() (fused) for them")
         self.current_actions = torch.clamp(actions.to(self._device, dtype=torch.float32), -self.clip_actions, self.clip_actions).contiguous()
         self.engine.apply_resets(self._goal_rand())
 

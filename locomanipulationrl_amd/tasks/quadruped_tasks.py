@@ -17,7 +17,7 @@ from typing import List, Optional
 from ..engine_config import MODE_LOCO, MODE_MANI, EngineParams
 from ..robot.quadruped_robot import (QuadrupedRobotOVFixedBaseOmni, QuadrupedRobotOVOmni, QuadrupedRobotVerticalOVFixedOmni,
                                      QuadrupedRobotVerticalOVOmni)
-from .base.rl_task import RLTask
+from .base.rl_task import CC_EXTRAS_KEYS, RLTask
 
 _TASK_INIT_Q = [-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4
 _H_CORNERS = [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04], [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]]
@@ -78,8 +78,8 @@ class _QuadrupedTask(RLTask):
         else:
             mu = mu_body
         rd = robot.robot_description
-        if rd.control_mode != "velocity":
-            raise NotImplementedError("only the velocity drive (the mode every task on this path uses) is implemented")
+        if rd.control_mode != "velocity" and not getattr(self, "custom_controller", False):
+            raise NotImplementedError("only the velocity drive and the custom PD controller are implemented")
         lo1, hi1 = self.min_joint_1_pos, self.max_joint_1_pos
         rlo1, rhi1 = self.reset_min_joint_1_pos, self.reset_max_joint_1_pos
         if self.mirrored_dof1_limits:
@@ -106,6 +106,14 @@ class _QuadrupedTask(RLTask):
             d1_pen=d1_pen, d1_rst=d1_rst, h_base=float(self.baseline_height), h_corner=float(self.baseline_corner_height),
             h_knee=float(self.baseline_knee_height), corner=[list(c) for c in self.corner_points],
         )
+        if getattr(self, "custom_controller", False):      # quadruped_pose_control_custom_controller.py:24-52,88-97
+            base.update(variant=1, num_obs=88, kd=float(self.control_kd), pd_kp=float(self.control_kp), joint_damping=float(self.joint_damping),
+                        tau_max=float(self.max_effort), act_scale_se=float(self.action_scale), se_lo=list(self.min_joint_pos_swing_ext),
+                        se_hi=list(self.max_joint_pos_swing_ext), init_se=list(self.init_joint_pos_swing_ext),
+                        substeps=int(self.control_decimal) + int(self.control_frequency_inv), torque_div=float(self.control_decimal),
+                        power_scale=float(self.mechanical_power_penalty_scale), target_err_scale=float(self.position_target_error_penalty_scale),
+                        rot_dec_scale=float(self.rot_dist_decreasing_reward_scale), rot_dec_thresh=float(self.no_rot_dist_decreasing_reward_thresh),
+                        cc_update_last_tgt=int(self.update_last_targets))
         base.update(kw)
         return EngineParams(**base)
 
@@ -242,3 +250,71 @@ class JointLocomanipulationVertical(JointLocomanipulation):
         _QuadrupedTask.__init__(self, sim_config, name, env, offset)
         self._single_task_num_envs = self._num_envs // 2
         assert self._single_task_num_envs * 2 == self._num_envs and self._single_task_num_envs % 16 == 0
+
+
+class _CustomControllerMixin:
+    """Custom-controller task family: explicit PD actuator re-evaluated every physics sub-step, swing / extension
+    action space, 88 observations, mechanical-power / target-error reward terms.  Class constants are the reference's
+    (quadruped_pose_control_custom_controller.py:24-52,67-108)."""
+    custom_controller = True
+    cc_extras_keys = CC_EXTRAS_KEYS
+    _num_observations = 88
+    max_effort = 1.5
+    control_kp = 4.5
+    control_kd = 0.2
+    joint_damping = 0.008
+    joint_friction = 0.007            # not modelled (DESIGN.md 3.3)
+    action_scale = 0.1
+    control_decimal = 4
+    min_joint_pos_swing_ext = [-2.35, -0.78, -0.78, -2.35, -2.09, 0.52, 1.05, 0.52, 1.05, 0.52, -2.09, 0.52]
+    max_joint_pos_swing_ext = [0.78, 2.35, 2.35, 0.78, -1.05, 2.09, 2.09, 2.09, 2.09, 2.09, -1.05, 2.09]
+    init_joint_pos_swing_ext = [-1.2, 1.2, 1.2, -1.2, -1.57, 0.7, 1.57, 0.7, 1.57, 0.7, -1.57, 0.7]
+    joint_acc_scale = -0.00015
+    action_rate_scale = -0.01
+    mechanical_power_penalty_scale = -0.02
+    position_target_error_penalty_scale = -0.05
+    rot_dist_decreasing_reward_scale = 0.0
+    no_rot_dist_decreasing_reward_thresh = 0.3
+    max_consecutive_successes = 20
+    update_last_targets = True
+
+
+class QuadrupedPoseControlCustomController(_CustomControllerMixin, _QuadrupedTask):
+    """tasks/quadruped_pose_control_tasks/quadruped_pose_control_custom_controller.py: class-default pose, base at z 0.18,
+    goal fixed at yaw 1.57 (:67-78), dt 0.005, 4 in-task + 1 wrapper sub-steps per action, 500-step episodes."""
+    min_roll, max_roll, min_pitch, max_pitch, min_yaw, max_yaw = 0.0, 0.0, 0.0, 0.0, 1.57, 1.57
+
+    def __init__(self, sim_config, name="QuadrupedPoseControlCustomController", env=None, offset=None) -> None:
+        self.robot_locomotion = QuadrupedRobotOVOmni()
+        self.robot_locomotion.robot_description.control_mode = "effort"          # :127
+        super().__init__(sim_config, name, env, offset)
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._loco_params(self.robot_locomotion)]
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory); self.robot_locomotion.bind(e); return e
+
+    @property
+    def current_joint_position_targets_se(self): return self.engine.state[90:102].T
+    @property
+    def last_joint_position_targets(self): return self.engine.state[102:114].T
+
+
+class QuadrupedManipulatePlateCustomController(_CustomControllerMixin, _QuadrupedTask):
+    """tasks/quadruped_manipulate_plate/quadruped_manipulate_plate_custom_controller.py: plate dropped from z 0.18; its
+    last_joint_position_targets are never refreshed after reset (only :378)."""
+    default_obj_position = [0.0, 0.0, 0.18]
+    update_last_targets = False
+
+    def __init__(self, sim_config, name="QuadrupedManipulatePlateCustomController", env=None, offset=None) -> None:
+        self.robot_manipulation = QuadrupedRobotOVFixedBaseOmni()
+        rd = self.robot_manipulation.robot_description
+        rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = [0.0, 0.0, 0.0]; rd.control_mode = "effort"
+        super().__init__(sim_config, name, env, offset)
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._mani_params(self.robot_manipulation, self.default_obj_position)]
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory); self.robot_manipulation.bind(e); return e

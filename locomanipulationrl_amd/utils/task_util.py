@@ -6,7 +6,8 @@ from .config import SimConfig
 
 def task_map():
     from ..tasks.quadruped_tasks import (JointLocomanipulation, JointLocomanipulationVertical, QuadrupedManipulatePlate,
-                                          QuadrupedManipulatePlateVertical, QuadrupedPoseControl, QuadrupedPoseControlVertical)
+                                          QuadrupedManipulatePlateCustomController, QuadrupedManipulatePlateVertical, QuadrupedPoseControl,
+                                          QuadrupedPoseControlCustomController, QuadrupedPoseControlVertical)
     return {
         "JointLocomanipulation": JointLocomanipulation,
         "QuadrupedPoseControl": QuadrupedPoseControl,
@@ -14,6 +15,8 @@ def task_map():
         "QuadrupedPoseControlVertical": QuadrupedPoseControlVertical,
         "QuadrupedManipulatePlateVertical": QuadrupedManipulatePlateVertical,
         "JointLocomanipulationVertical": JointLocomanipulationVertical,
+        "QuadrupedPoseControlCustomController": QuadrupedPoseControlCustomController,
+        "QuadrupedManipulatePlateCustomController": QuadrupedManipulatePlateCustomController,
     }
 
 

@@ -21,7 +21,7 @@ class OracleEngine:
         self.cnt = torch.zeros((6, self.N), dtype=torch.int64)
         self.num_obs = self.params[0].num_obs
         self.obs_buf = torch.zeros((self.N, self.num_obs)); self.states_buf = torch.zeros((self.N, 93)); self.rew_buf = torch.zeros(self.N)
-        self.extras_buf = torch.zeros(10); self.terms = torch.zeros((11, self.N)); self.stats_i64 = torch.zeros(6, dtype=torch.int64)
+        self.extras_buf = torch.zeros(13); self.terms = torch.zeros((11, self.N)); self.stats_i64 = torch.zeros(6, dtype=torch.int64)
         self._sr = [0.0, 0.0, 0.0]
         self._sync_out()
 
@@ -50,6 +50,7 @@ class OracleEngine:
             self.stats_i64[2 * w] = ns; self.stats_i64[2 * w + 1] = nr
             self.extras_buf[7 + w] = self._sr[w]
         self.extras_buf[:7] = torch.as_tensor(means.astype(np.float32))
+        self.extras_buf[10:13] = torch.as_tensor(terms[:, 8:11].mean(0).astype(np.float32))
         self._sync_out()
         out_obs, out_states, out_rew, out_resets, out_extras = outs
         c = self.clip_obs

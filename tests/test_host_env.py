@@ -79,15 +79,23 @@ def test_staged_api_equals_fused_step():
         assert torch.allclose(o1["obs"], ob2, atol=2e-5) and torch.allclose(r1, r2, atol=1e-4) and torch.equal(d1, d2)
 
 
-@pytest.mark.parametrize("task", ["QuadrupedManipulatePlate", "QuadrupedPoseControlVertical", "QuadrupedManipulatePlateVertical"])
+@pytest.mark.parametrize("task", ["QuadrupedManipulatePlate", "QuadrupedPoseControlVertical", "QuadrupedManipulatePlateVertical",
+                                  "QuadrupedPoseControlCustomController", "QuadrupedManipulatePlateCustomController"])
 def test_other_tasks_run(task):
     env = make(task, 16)
-    env.reset()
+    o = env.reset()
+    cc = "CustomController" in task
+    assert o["obs"].shape == (16, 88 if cc else 64) and env.observation_space.shape == ((88,) if cc else (64,))
     g = torch.Generator().manual_seed(1)
     for t in range(30):
         o, rew, resets, _ = env.step(torch.rand(16, 12, generator=g) * 2 - 1)
         assert torch.isfinite(o["obs"]).all() and torch.isfinite(rew).all()
     assert float(rew.min()) > -50
+    if cc:
+        _, _, _, extras = env.step(torch.zeros(16, 12))
+        assert "env/rewards/mechanical_power_penalty" in extras and float(extras["env/rewards/mechanical_power_penalty"]) <= 0
+        with pytest.raises(NotImplementedError):
+            env._task.pre_physics_step(torch.zeros(16, 12))
 
 
 def test_cotrain_layout():

@@ -14,7 +14,7 @@ def run(task_name, N, steps=300, warmup=50):
     g = torch.Generator(device="cuda").manual_seed(0)
     pool = [torch.rand(N, 12, device="cuda", generator=g) * 2 - 1 for _ in range(16)]
     o = (torch.empty(N, 64, device="cuda"), torch.empty(N, 93, device="cuda"), torch.empty(N, device="cuda"),
-         torch.empty(N, dtype=torch.int64, device="cuda"), torch.empty(10, device="cuda"))
+         torch.empty(N, dtype=torch.int64, device="cuda"), torch.empty(13, device="cuda"))
     for t in range(warmup): eng.step(pool[t % 16], None, *o)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for t in range(steps): eng.step(pool[t % 16], None, *o)

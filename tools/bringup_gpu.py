@@ -70,7 +70,7 @@ def main():
         for t in range(3):
             obs, states, rew, terms = o.step(phys, task, cnt, act.astype(np.float64), seed=42)
             oo = torch.empty(N, 64, device="cuda"); ss = torch.empty(N, 93, device="cuda"); rr = torch.empty(N, device="cuda")
-            rs = torch.empty(N, dtype=torch.int64, device="cuda"); ex = torch.empty(10, device="cuda")
+            rs = torch.empty(N, dtype=torch.int64, device="cuda"); ex = torch.empty(13, device="cuda")
             eng2.step(torch.as_tensor(act, device="cuda"), None, oo, ss, rr, rs, ex)
             torch.cuda.synchronize()
             print(f"[mode {mode}] step {t}: obs diff {np.abs(oo.cpu().numpy()-np.clip(obs,-5,5)).max():.2e} states {np.abs(ss.cpu().numpy()-np.clip(states,-5,5)).max():.2e} "
@@ -80,7 +80,7 @@ def main():
         engb = Engine(rm, [ep], Nb)
         a = torch.rand(Nb, 12, device="cuda") * 2 - 1
         oo = torch.empty(Nb, 64, device="cuda"); ss = torch.empty(Nb, 93, device="cuda"); rr = torch.empty(Nb, device="cuda")
-        rs = torch.empty(Nb, dtype=torch.int64, device="cuda"); ex = torch.empty(10, device="cuda")
+        rs = torch.empty(Nb, dtype=torch.int64, device="cuda"); ex = torch.empty(13, device="cuda")
         for _ in range(20): engb.step(a, None, oo, ss, rr, rs, ex)
         torch.cuda.synchronize(); t0 = time.time()
         K = 200
