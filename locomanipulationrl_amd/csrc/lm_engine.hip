@@ -293,10 +293,10 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
 
 // One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
 // robot base is fixed at (Rb, pb).
-template <int MODE>
+template <int MODE, int VAR>
 LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb, const Stash& St,
                     FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3], float tau_acc[3]) {
-  const float dt = P->dt, kd = P->kd, tmax = P->tau_max, cj = P->joint_damping;
+  const float dt = P->dt, kd = P->kd, tmax = P->tau_max, cj = VAR ? P->joint_damping : 0.f;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
   float bn;
   {
@@ -466,7 +466,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) {      // driven joints are speed-limited like PhysX's maxJointVelocity (config_module_joints.py:11,61-69)
-    tau_acc[a] += sat[a] ? tsat[a] : kd * (tgt[a] - qdn[a]);      // drive torque applied over this sub-step
+    if (VAR) tau_acc[a] += sat[a] ? tsat[a] : kd * (tgt[a] - qdn[a]);      // drive torque applied over this sub-step
     float v = fminf(fmaxf(qdn[a], -P->max_joint_vel), P->max_joint_vel);
     qd[a] = v; q[a] = fmaf(dt, v, q[a]);
   }
@@ -487,7 +487,7 @@ struct TaskIn {
 struct TaskState { float lact[3]; V3 ltip; Q4 goal; int succ, consec, greset, reset, progress; float ltgt[3]; float lrd; };
 struct TaskOut { float rew; float terms[11]; };
 
-template <int MODE>
+template <int MODE, int VAR>
 LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const TaskIn& I, TaskState& S, TaskOut& O,
                       float* sObs, float* sSt) {
   S.progress += 1;
@@ -505,7 +505,7 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   }
   V3 btip = mulT(Rr, I.tipw - pr);
   Q4 qd_ = qmul(oq, qconj(S.goal));
-  const bool var1 = (P->variant == 1); const int NO = P->num_obs;
+  constexpr bool var1 = (VAR == 1); const int NO = var1 ? LM_MAX_OBS : 64;
   float fl = (qd_.w < 0.f && !var1) ? -1.f : 1.f;        // the custom-controller tasks do not flip the sign (…custom_controller.py:429-431)
   Q4 qf; qf.w = fl * qd_.w; qf.x = fl * qd_.x; qf.y = fl * qd_.y; qf.z = fl * qd_.z;
   M3 Ro = quat_to_mat(oq.w, oq.x, oq.y, oq.z);
@@ -661,7 +661,7 @@ struct StepArgs {
   int nsub;         // < 0: params.substeps, otherwise that many sub-steps (0 = read-back + task layer only)
 };
 
-template <int MODE>
+template <int MODE, int VAR>
 LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const float* sTab, float* sObs, float* sSt, float4* sStash) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
   const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
@@ -699,12 +699,12 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   float tau_acc[3] = {0.f, 0.f, 0.f}, tgtq[3] = {0.f, 0.f, 0.f};
-  const bool var1 = (P->variant == 1);
+  constexpr bool var1 = (VAR == 1);
   const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
   if (!var1) {
     // ---- take_action (robot.py:452-454): velocity targets
     float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
-    for (int s = 0; s < nsub; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+    for (int s = 0; s < nsub; s++) substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
   } else {
     // ---- custom-controller tasks (quadruped_pose_control_custom_controller.py:255-307): the action integrates the swing / extension
     // position targets; the actuator torque  clamp(kp (q* - q) - kd qd, +-tau_max)  is re-evaluated every sub-step.  It is the same drive
@@ -721,7 +721,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     const float g = P->pd_kp / P->kd;
     for (int s = 0; s < nsub; s++) {
       float tgt[3] = {g * (tgtq[0] - q[0]), g * (tgtq[1] - q[1]), g * (tgtq[2] - q[2])};
-      substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+      substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
     }
   }
   // ---- task-layer state
@@ -788,7 +788,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a];
     I.torque[a] = var1 ? tau_acc[a] / P->torque_div : 0.f; I.tgtq[a] = tgtq[a]; }      // logged torque = sum over sub-steps / control_decimal (:307)
   TaskOut O;
-  task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
+  task_eval<MODE, VAR>(P, limb, envl, I, S, O, sObs, sSt);
   if (blown) S.reset = 1;
   // ---- store state
   if (active) {
@@ -822,7 +822,8 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   load_table(A.table, sTab, threadIdx.x);
   const int env0 = blockIdx.x * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
-  if (P->mode == LM_MODE_LOCO) step_body<0>(A, P, sTab, sObs, sSt, sStash); else step_body<1>(A, P, sTab, sObs, sSt, sStash);
+  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0>(A, P, sTab, sObs, sSt, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) step_body<0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1>(A, P, sTab, sObs, sSt, sStash); }
 }
 
 // means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps
@@ -947,7 +948,7 @@ LM_DEV void store_phys(float* st, int N, int env, int limb, const FreeBody& F, c
   }
 }
 
-template <int MODE>
+template <int MODE, int VAR>
 LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sTab, const float* targets, int n, float4* sStash) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
   Stash St; St.base = sStash; St.lane = lane;
@@ -959,7 +960,7 @@ LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sT
   M3 Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   float tau_acc[3] = {0.f, 0.f, 0.f};
-  for (int s = 0; s < n; s++) substep<MODE>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+  for (int s = 0; s < n; s++) substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
   if (active) store_phys<MODE>(A.state, N, env, limb, F, q, qd);
 }
 __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* targets, int n) {
@@ -967,7 +968,8 @@ __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* target
   __shared__ float4 sStash[STASH_SLOTS * 64];
   load_table(A.table, sTab, threadIdx.x);
   const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
-  if (P->mode == LM_MODE_LOCO) substeps_body<0>(A, P, sTab, targets, n, sStash); else substeps_body<1>(A, P, sTab, targets, n, sStash);
+  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) substeps_body<0, 0>(A, P, sTab, targets, n, sStash); else substeps_body<1, 0>(A, P, sTab, targets, n, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) substeps_body<0, 1>(A, P, sTab, targets, n, sStash); else substeps_body<1, 1>(A, P, sTab, targets, n, sStash); }
 }
 
 __global__ void __launch_bounds__(64) k_fk(StepArgs A, float* tips, float* knees) {
@@ -1048,7 +1050,7 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
   S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
   S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
   S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; int episode = (int)cnt[5 * (size_t)N + env];
-  task_eval<MODE>(P, limb, envl, I, S, O, sObs, sSt);
+  if (P->variant == 1) task_eval<MODE, 1>(P, limb, envl, I, S, O, sObs, sSt); else task_eval<MODE, 0>(P, limb, envl, I, S, O, sObs, sSt);
   if (active) {
     for (int a = 0; a < 3; a++) { st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a]; st[(size_t)(R_LTGT + jj[a]) * N + env] = S.ltgt[a]; }
     if (limb == 0) st[(size_t)R_LRD * N + env] = S.lrd;
