@@ -59,16 +59,19 @@ typedef struct lm_params {
   float clip_obs, clip_actions;
   int32_t max_reset_counts;
   /* custom-controller task family (quadruped_pose_control_custom_controller.py:24-52,88-97,255-307) */
-  int32_t variant;           /* 0 velocity-drive tasks, 1 custom-controller tasks */
+  int32_t variant;           /* 0 velocity-drive tasks, 1 custom-controller tasks, 2 position-control tasks (same PD actuator and swing/extension
+                                actions; 64-wide observation with the scaled joint targets in place of the actions; reward of variant 0;
+                                quadruped_pose_control_position_control.py:24-118,438-455, joint_locomanipulation_position_control.py:37-44,365-408) */
   int32_t num_obs;           /* 64 / 88 */
   float pd_kp, joint_damping, act_scale_se;
   float se_lo[12], se_hi[12], init_se[12];
   float torque_div, power_scale, target_err_scale, rot_dec_scale, rot_dec_thresh;
   int32_t cc_update_last_tgt;
+  int32_t acc_substeps;      /* variants 1/2: trailing sub-steps the joint acceleration spans (controlFrequencyInv; robot.py:289-291) */
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */
-  float ctrl_dt_inv;
+  float ctrl_dt_inv, acc_dt_inv;
 } lm_params;
 
 typedef struct lm_engine lm_engine;   /* opaque */

@@ -505,7 +505,7 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   }
   V3 btip = mulT(Rr, I.tipw - pr);
   Q4 qd_ = qmul(oq, qconj(S.goal));
-  constexpr bool var1 = (VAR == 1); const int NO = var1 ? LM_MAX_OBS : 64;
+  constexpr bool var1 = (VAR == 1), var2 = (VAR == 2), pd = (VAR >= 1); const int NO = var1 ? LM_MAX_OBS : 64;
   float fl = (qd_.w < 0.f && !var1) ? -1.f : 1.f;        // the custom-controller tasks do not flip the sign (…custom_controller.py:429-431)
   Q4 qf; qf.w = fl * qd_.w; qf.x = fl * qd_.x; qf.y = fl * qd_.y; qf.z = fl * qd_.z;
   M3 Ro = quat_to_mat(oq.w, oq.x, oq.y, oq.z);
@@ -529,7 +529,7 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     int j = jj[a];
-    ob[16 + j] = P->s_q * I.q[a]; ob[28 + j] = P->s_qd * I.qd[a]; ob[40 + j] = I.act[a]; ob[52 + j] = S.lact[a];
+    ob[16 + j] = P->s_q * I.q[a]; ob[28 + j] = P->s_qd * I.qd[a]; ob[40 + j] = var2 ? 0.3f * I.tgtq[a] : I.act[a]; ob[52 + j] = var2 ? 0.3f * S.ltgt[a] : S.lact[a];      // position-control tasks: targets replace the actions (…position_control.py:438-453)
     st[13 + j] = P->s_q * I.q[a]; st[25 + j] = P->s_qd * I.qd[a]; st[69 + j] = I.act[a]; st[81 + j] = S.lact[a];
     if (var1) { ob[64 + j] = 0.3f * I.tgtq[a]; ob[76 + j] = 0.3f * S.ltgt[a]; }      // :432-455
   }
@@ -589,7 +589,7 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   O.rew = total;
   O.terms[0] = rot_rew; O.terms[1] = trans; O.terms[2] = accp; O.terms[3] = rate; O.terms[4] = bonus; O.terms[5] = limp; O.terms[6] = fallp; O.terms[7] = (float)cgr;
   O.terms[8] = powp; O.terms[9] = terr; O.terms[10] = rdec;
-  if (var1 && P->cc_update_last_tgt) { S.ltgt[0] = I.tgtq[0]; S.ltgt[1] = I.tgtq[1]; S.ltgt[2] = I.tgtq[2]; }      // :723-725
+  if (pd && P->cc_update_last_tgt) { S.ltgt[0] = I.tgtq[0]; S.ltgt[1] = I.tgtq[1]; S.ltgt[2] = I.tgtq[2]; }      // :723-725
 }
 
 // shared tail: write staged obs / states, reward, counters, per-block partial sums
@@ -698,10 +698,10 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   }
   M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
-  float tau_acc[3] = {0.f, 0.f, 0.f}, tgtq[3] = {0.f, 0.f, 0.f};
-  constexpr bool var1 = (VAR == 1);
+  float tau_acc[3] = {0.f, 0.f, 0.f}, tgtq[3] = {0.f, 0.f, 0.f}, qda[3] = {0.f, 0.f, 0.f}; bool qda_set = false;
+  constexpr bool pd = (VAR >= 1);
   const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
-  if (!var1) {
+  if (!pd) {
     // ---- take_action (robot.py:452-454): velocity targets
     float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
     for (int s = 0; s < nsub; s++) substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
@@ -720,6 +720,9 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     tgtq[0] = se[0]; tgtq[1] = se[1] + 0.5f * se[2]; tgtq[2] = se[1] - 0.5f * se[2];      // dof1, dof2 = swing + ext/2, dof3 = swing - ext/2
     const float g = P->pd_kp / P->kd;
     for (int s = 0; s < nsub; s++) {
+      // update_joint_states() runs after every in-task sub-step (…custom_controller.py:296-297): the joint acceleration spans only the
+      // trailing acc_substeps (= controlFrequencyInv) sub-steps (robot.py:289-291)
+      if (s == nsub - P->acc_substeps) { qda[0] = qd[0]; qda[1] = qd[1]; qda[2] = qd[2]; qda_set = true; }
       float tgt[3] = {g * (tgtq[0] - q[0]), g * (tgtq[1] - q[1]), g * (tgtq[2] - q[2])};
       substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
     }
@@ -733,7 +736,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   S.ltip = v3(st[(size_t)(R_LTIP + 3 * limb) * N + env], st[(size_t)(R_LTIP + 3 * limb + 1) * N + env], st[(size_t)(R_LTIP + 3 * limb + 2) * N + env]);
   S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
   S.lrd = 0.f; S.ltgt[0] = S.ltgt[1] = S.ltgt[2] = 0.f;
-  if (var1) {
+  if (pd) {
 #pragma unroll
     for (int a = 0; a < 3; a++) S.ltgt[a] = st[(size_t)(R_LTGT + jj[a]) * N + env];
     S.lrd = st[(size_t)R_LRD * N + env];
@@ -748,7 +751,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     for (int a = 0; a < 3; a++) { S.lact[a] = 0.f; lqd[a] = 0.f; }
     S.ltip = v3(P->default_tip[3 * limb], P->default_tip[3 * limb + 1], P->default_tip[3 * limb + 2]);
     S.succ = 0; S.consec = 0; S.greset = 0; S.reset = 0; S.progress = 0; episode += 1;
-    if (var1) {      // :371-384
+    if (pd) {      // :371-384
 #pragma unroll
       for (int a = 0; a < 3; a++) S.ltgt[a] = P->init_q[jj[a]];
       Q4 qb; qb.w = (MODE == 0) ? P->init_base_quat[0] : 1.f; qb.x = (MODE == 0) ? -P->init_base_quat[1] : 0.f;
@@ -785,8 +788,8 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
     I.tipw = pb + mul(Rb, x); I.knee2 = pb + mul(Rb, K.o2); I.knee3 = pb + mul(Rb, K.o3);
   }
 #pragma unroll
-  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a];
-    I.torque[a] = var1 ? tau_acc[a] / P->torque_div : 0.f; I.tgtq[a] = tgtq[a]; }      // logged torque = sum over sub-steps / control_decimal (:307)
+  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (pd && qda_set) ? (qd[a] - qda[a]) * P->acc_dt_inv : (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a];
+    I.torque[a] = pd ? tau_acc[a] / P->torque_div : 0.f; I.tgtq[a] = tgtq[a]; }      // logged torque = sum over sub-steps / control_decimal (:307)
   TaskOut O;
   task_eval<MODE, VAR>(P, limb, envl, I, S, O, sObs, sSt);
   if (blown) S.reset = 1;
@@ -798,7 +801,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
       st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a]; st[(size_t)(R_LQD + jj[a]) * N + env] = qd[a];
     }
     st[(size_t)(R_LTIP + 3 * limb) * N + env] = S.ltip.x; st[(size_t)(R_LTIP + 3 * limb + 1) * N + env] = S.ltip.y; st[(size_t)(R_LTIP + 3 * limb + 2) * N + env] = S.ltip.z;
-    if (var1) {
+    if (pd) {
 #pragma unroll
       for (int a = 0; a < 3; a++) st[(size_t)(R_LTGT + jj[a]) * N + env] = S.ltgt[a];
       if (limb == 0) st[(size_t)R_LRD * N + env] = S.lrd;
@@ -823,7 +826,8 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   const int env0 = blockIdx.x * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0>(A, P, sTab, sObs, sSt, sStash); }
-  else { if (P->mode == LM_MODE_LOCO) step_body<0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1>(A, P, sTab, sObs, sSt, sStash); }
+  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1>(A, P, sTab, sObs, sSt, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2>(A, P, sTab, sObs, sSt, sStash); }
 }
 
 // means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps
@@ -1038,7 +1042,7 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
     // custom-controller tasks: integrate the swing / extension targets like pre_physics_step (:255-276)
     float se[3];
     for (int a = 0; a < 3; a++) { se[a] = st[(size_t)(R_SE + jj[a]) * N + env];
-      if (P->variant == 1) { se[a] = fminf(fmaxf(se[a] + I.act[a] * P->act_scale_se, P->se_lo[jj[a]]), P->se_hi[jj[a]]); if (active) st[(size_t)(R_SE + jj[a]) * N + env] = se[a]; } }
+      if (P->variant >= 1) { se[a] = fminf(fmaxf(se[a] + I.act[a] * P->act_scale_se, P->se_lo[jj[a]]), P->se_hi[jj[a]]); if (active) st[(size_t)(R_SE + jj[a]) * N + env] = se[a]; } }
     I.tgtq[0] = se[0]; I.tgtq[1] = se[1] + 0.5f * se[2]; I.tgtq[2] = se[1] - 0.5f * se[2];
     S.lrd = st[(size_t)R_LRD * N + env];
   }
@@ -1050,7 +1054,8 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
   S.goal.w = st[(size_t)(R_GOAL + 0) * N + env]; S.goal.x = st[(size_t)(R_GOAL + 1) * N + env]; S.goal.y = st[(size_t)(R_GOAL + 2) * N + env]; S.goal.z = st[(size_t)(R_GOAL + 3) * N + env];
   S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
   S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; int episode = (int)cnt[5 * (size_t)N + env];
-  if (P->variant == 1) task_eval<MODE, 1>(P, limb, envl, I, S, O, sObs, sSt); else task_eval<MODE, 0>(P, limb, envl, I, S, O, sObs, sSt);
+  if (P->variant == 1) task_eval<MODE, 1>(P, limb, envl, I, S, O, sObs, sSt); else if (P->variant == 2) task_eval<MODE, 2>(P, limb, envl, I, S, O, sObs, sSt);
+  else task_eval<MODE, 0>(P, limb, envl, I, S, O, sObs, sSt);
   if (active) {
     for (int a = 0; a < 3; a++) { st[(size_t)(R_LACT + jj[a]) * N + env] = S.lact[a]; st[(size_t)(R_LTGT + jj[a]) * N + env] = S.ltgt[a]; }
     if (limb == 0) st[(size_t)R_LRD * N + env] = S.lrd;
@@ -1091,6 +1096,7 @@ static void derive_params(lm_params* p) {
   }
   for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) p->plate_phi[6 * i + j] = (float)A[i][6 + j];
   p->ctrl_dt_inv = (float)(1.0 / ((double)p->dt * (double)p->substeps));
+  p->acc_dt_inv = (float)(1.0 / ((double)p->dt * (double)(p->acc_substeps > 0 ? p->acc_substeps : 1)));
 }
 
 extern "C" {
@@ -1108,9 +1114,9 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     const lm_params& p = params[t];
     if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
       return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
-    if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || (p.variant != 0 && p.variant != 1) ||
-        (p.variant == 1) != (p.num_obs == LM_MAX_OBS) || (p.variant == 1 && !(p.kd > 0 && p.torque_div > 0)))
-      return fail(LM_EINVAL, "lm_create: invalid variant / num_obs (64 for velocity-drive tasks, 88 for custom-controller tasks, equal across tasks)");
+    if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || p.variant < 0 || p.variant > 2 ||
+        (p.variant == 1) != (p.num_obs == LM_MAX_OBS) || (p.variant >= 1 && !(p.kd > 0 && p.torque_div > 0 && p.acc_substeps >= 1 && p.acc_substeps <= p.substeps)))
+      return fail(LM_EINVAL, "lm_create: invalid variant / num_obs (64 for velocity-drive and position-control tasks, 88 for custom-controller tasks, equal across tasks) or acc_substeps");
   }
   lm_engine* h = new (std::nothrow) lm_engine();
   if (!h) return fail(LM_ENOMEM, "lm_create: host allocation failed");

@@ -92,7 +92,8 @@ class EngineParams:
     corner: List[List[float]] = field(default_factory=lambda: [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04],
                                                                [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]])
     # ---- custom-controller task family (quadruped_pose_control_custom_controller.py:24-52,88-97)
-    variant: int = 0                    # 0 velocity-drive tasks, 1 custom-controller (PD actuator, swing/extension actions, obs 88)
+    variant: int = 0                    # 0 velocity-drive tasks, 1 custom-controller (PD actuator, swing/extension actions, obs 88),
+                                        # 2 position-control (same actuator / actions; obs 64 with the targets in place of the actions; base reward)
     num_obs: int = 64
     pd_kp: float = 4.5
     joint_damping: float = 0.0
@@ -105,6 +106,7 @@ class EngineParams:
     target_err_scale: float = -0.05
     rot_dec_scale: float = 0.0
     rot_dec_thresh: float = 0.3
+    acc_substeps: int = 1               # variants 1/2: the joint acceleration spans the trailing controlFrequencyInv sub-steps (robot.py:289-291)
     cc_update_last_tgt: int = 1         # loco: last targets follow the targets (:723-725); the mani variant never updates them after reset
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
@@ -147,3 +149,30 @@ def loco_cc_params(**kw) -> EngineParams:
 def mani_cc_params(**kw) -> EngineParams:
     """QuadrupedManipulatePlateCustomController: plate dropped from z 0.18 onto the inverted fixed robot."""
     return replace(EngineParams(mode=MODE_MANI), **_cc(init_plate_pos=[0.0, 0.0, 0.18], cc_update_last_tgt=0, **kw))
+
+
+_PC_INIT_SE = [-1.57, 1.57, 1.57, -1.57, -1.57, 1.05, 1.57, 1.05, 1.57, 1.05, -1.57, 1.05]
+
+
+def _pc(**kw):
+    """Constants shared by the position-control tasks (quadruped_pose_control_position_control.py:24-118,148-149,183-199,261;
+    cfg/task/QuadrupedPoseControlPositionControl.yaml:13,18-19).  Same PD actuator and swing/extension action space as the
+    custom-controller tasks; 64-wide observation with the scaled joint position targets in place of the actions; the reward of
+    the velocity-drive tasks; the last-target buffer is only written at reset.  The committed `actions[:] = 0.0` debug line
+    (:261) that freezes the targets in the two single-task files is not reproduced."""
+    base = dict(variant=2, num_obs=64, dt=0.005, substeps=5, kd=0.2, pd_kp=4.5, joint_damping=0.008, tau_max=1.5, act_scale_se=0.1,
+                torque_div=4.0, init_se=list(_PC_INIT_SE), cc_update_last_tgt=0, acc_substeps=1, power_scale=0.0, target_err_scale=0.0,
+                goal_lo=[-0.5, -0.5, -3.14], goal_hi=[0.5, 0.5, 3.14], succ_thresh=0.1, max_consec=15, max_episode=500)
+    base.update(kw)
+    return base
+
+
+def loco_pc_params(**kw) -> EngineParams:
+    """QuadrupedPoseControlPositionControl."""
+    return replace(EngineParams(), **_pc(**kw))
+
+
+def mani_pc_params(**kw) -> EngineParams:
+    """QuadrupedManipulatePlatePositionControl: inverted fixed robot at z 0.3, plate dropped from z 0.44, 450-step episodes
+    (quadruped_manipulate_plate_position_control.py:122-124,177; cfg/task/QuadrupedManipulatePlatePositionControl.yaml:18)."""
+    return replace(EngineParams(mode=MODE_MANI), **_pc(fixed_base_pos=[0.0, 0.0, 0.3], init_plate_pos=[0.0, 0.0, 0.44], max_episode=450, **kw))

@@ -53,12 +53,12 @@ class LmParams(C.Structure):
         ("variant", C.c_int32), ("num_obs", C.c_int32), ("pd_kp", C.c_float), ("joint_damping", C.c_float), ("act_scale_se", C.c_float),
         ("se_lo", C.c_float * 12), ("se_hi", C.c_float * 12), ("init_se", C.c_float * 12),
         ("torque_div", C.c_float), ("power_scale", C.c_float), ("target_err_scale", C.c_float), ("rot_dec_scale", C.c_float),
-        ("rot_dec_thresh", C.c_float), ("cc_update_last_tgt", C.c_int32),
-        ("plate_si", C.c_float * 10), ("plate_phi", C.c_float * 36), ("ctrl_dt_inv", C.c_float),
+        ("rot_dec_thresh", C.c_float), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
+        ("plate_si", C.c_float * 10), ("plate_phi", C.c_float * 36), ("ctrl_dt_inv", C.c_float), ("acc_dt_inv", C.c_float),
     ]
 
 
-_DERIVED = {"plate_si", "plate_phi", "ctrl_dt_inv"}
+_DERIVED = {"plate_si", "plate_phi", "ctrl_dt_inv", "acc_dt_inv"}
 
 
 def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParams:

@@ -5,6 +5,8 @@
   QuadrupedManipulatePlate        tasks/quadruped_manipulate_plate/quadruped_manipulate_plate.py
   QuadrupedManipulatePlateVertical tasks/quadruped_manipulate_plate/quadruped_manipulate_plate_vertical.py
   JointLocomanipulation(/Vertical) tasks/joint_train_locomanipulation/joint_locomanipulation(_vertical).py
+  …CustomController               tasks/*/quadruped_*_custom_controller.py                  
+  …PositionControl                tasks/*/quadruped_*_position_control.py, joint_locomanipulation_position_control.py   
 
 The class attributes are the reference's (quadruped_pose_control.py:27-87); they are compiled into the
 engine's parameter block, so editing them on a subclass changes the kernels' behaviour exactly as it changes
@@ -107,7 +109,8 @@ class _QuadrupedTask(RLTask):
             h_knee=float(self.baseline_knee_height), corner=[list(c) for c in self.corner_points],
         )
         if getattr(self, "custom_controller", False):      # quadruped_pose_control_custom_controller.py:24-52,88-97
-            base.update(variant=1, num_obs=88, kd=float(self.control_kd), pd_kp=float(self.control_kp), joint_damping=float(self.joint_damping),
+            v = int(self.controller_variant)
+            base.update(variant=v, num_obs=88 if v == 1 else 64, acc_substeps=int(self.control_frequency_inv), kd=float(self.control_kd), pd_kp=float(self.control_kp), joint_damping=float(self.joint_damping),
                         tau_max=float(self.max_effort), act_scale_se=float(self.action_scale), se_lo=list(self.min_joint_pos_swing_ext),
                         se_hi=list(self.max_joint_pos_swing_ext), init_se=list(self.init_joint_pos_swing_ext),
                         substeps=int(self.control_decimal) + int(self.control_frequency_inv), torque_div=float(self.control_decimal),
@@ -205,15 +208,17 @@ class JointLocomanipulation(_QuadrupedTask):
     the goal to a single orientation and exits after recording two trajectories (:61-66,861-874); the ranges of
     the single tasks are used instead."""
     _num_states = 64
-    baseline_knee_height = -1.0e9          # the co-train is_done carries no knee test (joint_locomanipulation.py:712-770)
     default_obj_position = [0.0, 0.0, 0.68]
     mani_base_position = [0.0, 0.0, 0.5]
 
-    def __init__(self, sim_config, name="JointLocomanipulation", env=None, offset=None) -> None:
+    def _make_robots(self):
         self.robot_locomotion = QuadrupedRobotOVOmni()
         self.robot_manipulation = QuadrupedRobotOVFixedBaseOmni()
         rd = self.robot_manipulation.robot_description
         rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = list(self.mani_base_position)
+
+    def __init__(self, sim_config, name="JointLocomanipulation", env=None, offset=None) -> None:
+        self._make_robots()
         super().__init__(sim_config, name, env, offset)
         self._single_task_num_envs = self._num_envs // 2
         assert self._single_task_num_envs * 2 == self._num_envs, "Number of envs must be a multiplier of 2. "
@@ -257,6 +262,7 @@ class _CustomControllerMixin:
     action space, 88 observations, mechanical-power / target-error reward terms.  Class constants are the reference's
     (quadruped_pose_control_custom_controller.py:24-52,67-108)."""
     custom_controller = True
+    controller_variant = 1
     cc_extras_keys = CC_EXTRAS_KEYS
     _num_observations = 88
     max_effort = 1.5
@@ -318,3 +324,93 @@ class QuadrupedManipulatePlateCustomController(_CustomControllerMixin, _Quadrupe
 
     def create_engine(self, engine_factory=None):
         e = super().create_engine(engine_factory); self.robot_manipulation.bind(e); return e
+
+
+class _PositionControlMixin:
+    """Position-control task family: the PD actuator and swing / extension action space of the custom-controller
+    tasks, a 64-wide observation whose last 24 entries are the scaled current / reset joint position targets, states_buf aliasing
+    obs_buf, and the reward of the velocity-drive tasks (quadruped_pose_control_position_control.py:24-118,148-149,438-455).
+    The two single-task files carry a live `actions[:] = 0.0` (:261, a debug leftover that freezes the targets); that line is not
+    reproduced - set action_scale = 0 on a subclass to get it."""
+    custom_controller = True
+    controller_variant = 2
+    cc_extras_keys = []
+    _num_observations = 64
+    _num_states = 64
+    max_effort = 1.5
+    control_kp = 4.5
+    control_kd = 0.2
+    joint_damping = 0.008
+    joint_friction = 0.007            # not modelled (DESIGN.md 3.3)
+    action_scale = 0.1
+    control_decimal = 4
+    min_joint_pos_swing_ext = [-2.35, -0.78, -0.78, -2.35, -2.09, 0.52, 1.05, 0.52, 1.05, 0.52, -2.09, 0.52]
+    max_joint_pos_swing_ext = [0.78, 2.35, 2.35, 0.78, -1.05, 2.09, 2.09, 2.09, 2.09, 2.09, -1.05, 2.09]
+    init_joint_pos_swing_ext = [-1.57, 1.57, 1.57, -1.57, -1.57, 1.05, 1.57, 1.05, 1.57, 1.05, -1.57, 1.05]
+    mechanical_power_penalty_scale = 0.0
+    position_target_error_penalty_scale = 0.0
+    rot_dist_decreasing_reward_scale = 0.0
+    no_rot_dist_decreasing_reward_thresh = 0.3
+    update_last_targets = False       # last_joint_position_targets is only written by reset_idx (:380)
+    min_roll, max_roll, min_pitch, max_pitch, min_yaw, max_yaw = -0.5, 0.5, -0.5, 0.5, -3.14, 3.14
+    success_thresh = 0.1
+
+    @property
+    def current_joint_position_targets_se(self): return self.engine.state[90:102].T
+    @property
+    def last_joint_position_targets(self): return self.engine.state[102:114].T
+
+
+class QuadrupedPoseControlPositionControl(_PositionControlMixin, _QuadrupedTask):
+    """tasks/quadruped_pose_control_tasks/quadruped_pose_control_position_control.py (dt 0.005, 4 + 1 sub-steps, 500-step episodes)."""
+
+    def __init__(self, sim_config, name="QuadrupedPoseControlPositionControl", env=None, offset=None) -> None:
+        self.robot_locomotion = QuadrupedRobotOVOmni()
+        rd = self.robot_locomotion.robot_description
+        rd.init_joint_pos = list(_TASK_INIT_Q); rd.default_position = [0.0, 0.0, 0.14]; rd.control_mode = "effort"      # :123-133
+        super().__init__(sim_config, name, env, offset)
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._loco_params(self.robot_locomotion)]
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory); self.robot_locomotion.bind(e); return e
+
+
+class QuadrupedManipulatePlatePositionControl(_PositionControlMixin, _QuadrupedTask):
+    """tasks/quadruped_manipulate_plate/quadruped_manipulate_plate_position_control.py: inverted robot fixed at z 0.3, plate
+    dropped from z 0.44 (:122-124,177), 450-step episodes."""
+    default_obj_position = [0.0, 0.0, 0.44]
+
+    def __init__(self, sim_config, name="QuadrupedManipulatePlatePositionControl", env=None, offset=None) -> None:
+        self.robot_manipulation = QuadrupedRobotOVFixedBaseOmni()
+        rd = self.robot_manipulation.robot_description
+        rd.default_quaternion = [0.0, 1.0, 0.0, 0.0]; rd.default_position = [0.0, 0.0, 0.3]; rd.control_mode = "effort"
+        rd.init_joint_pos = list(_TASK_INIT_Q)
+        super().__init__(sim_config, name, env, offset)
+
+    def engine_params(self) -> List[EngineParams]:
+        return [self._mani_params(self.robot_manipulation, self.default_obj_position)]
+
+    def create_engine(self, engine_factory=None):
+        e = super().create_engine(engine_factory); self.robot_manipulation.bind(e); return e
+
+
+class JointLocomanipulationPositionControl(_PositionControlMixin, JointLocomanipulation):
+    """tasks/joint_train_locomanipulation/joint_locomanipulation_position_control.py: co-training with the PD actuator
+    (dt 1/240 s, control_decimal 7 + 1 sub-steps = 30 Hz control, :37-44,365-408), plate dropped from z 0.64 (:214)."""
+    control_decimal = 7
+    min_roll, max_roll, min_pitch, max_pitch, min_yaw, max_yaw = -0.4, 0.4, -0.4, 0.4, -1.57, 1.57      # :86-91
+    joint_acc_scale = -0.001
+    action_rate_scale = -0.03
+    success_bonus = 5
+    default_obj_position = [0.0, 0.0, 0.64]
+
+    def _make_robots(self):          # :131-157
+        JointLocomanipulation._make_robots(self)
+        for rd in (self.robot_locomotion.robot_description, self.robot_manipulation.robot_description):
+            rd.init_joint_pos = list(_TASK_INIT_Q); rd.control_mode = "effort"
+        self.robot_locomotion.robot_description.default_position = [0.0, 0.0, 0.14]
+
+    def __init__(self, sim_config, name="JointLocomanipulationPositionControl", env=None, offset=None) -> None:
+        JointLocomanipulation.__init__(self, sim_config, name, env, offset)

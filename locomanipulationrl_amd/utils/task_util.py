@@ -5,9 +5,11 @@ from .config import SimConfig
 
 
 def task_map():
-    from ..tasks.quadruped_tasks import (JointLocomanipulation, JointLocomanipulationVertical, QuadrupedManipulatePlate,
-                                          QuadrupedManipulatePlateCustomController, QuadrupedManipulatePlateVertical, QuadrupedPoseControl,
-                                          QuadrupedPoseControlCustomController, QuadrupedPoseControlVertical)
+    from ..tasks.quadruped_tasks import (JointLocomanipulation, JointLocomanipulationPositionControl, JointLocomanipulationVertical,
+                                          QuadrupedManipulatePlate, QuadrupedManipulatePlateCustomController,
+                                          QuadrupedManipulatePlatePositionControl, QuadrupedManipulatePlateVertical, QuadrupedPoseControl,
+                                          QuadrupedPoseControlCustomController, QuadrupedPoseControlPositionControl,
+                                          QuadrupedPoseControlVertical)
     return {
         "JointLocomanipulation": JointLocomanipulation,
         "QuadrupedPoseControl": QuadrupedPoseControl,
@@ -17,6 +19,9 @@ def task_map():
         "JointLocomanipulationVertical": JointLocomanipulationVertical,
         "QuadrupedPoseControlCustomController": QuadrupedPoseControlCustomController,
         "QuadrupedManipulatePlateCustomController": QuadrupedManipulatePlateCustomController,
+        "QuadrupedPoseControlPositionControl": QuadrupedPoseControlPositionControl,
+        "QuadrupedManipulatePlatePositionControl": QuadrupedManipulatePlatePositionControl,
+        "JointLocomanipulationPositionControl": JointLocomanipulationPositionControl,
     }
 
 

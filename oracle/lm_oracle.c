@@ -361,7 +361,7 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     const real* rb=readback+(size_t)e*LMO_READBACK; const real* act=actions+(size_t)e*12;
     real* tk=task+(size_t)e*LMO_TASK; int64_t* c=cnt+(size_t)e*LMO_CNT;
     real* ob=obs+(size_t)e*p->num_obs; real* st=states+(size_t)e*93; real* tr=terms+(size_t)e*LMO_TERMS;
-    const int var1=(p->variant==1); const real* torque=rb+87; real* se=tk+40; real* last_tgt=tk+52;
+    const int var1=(p->variant==1), var2=(p->variant==2), pd=(p->variant>=1); const real* torque=rb+87; real* se=tk+40; real* last_tgt=tk+52;
     real tgtq[12];   /* current joint position targets from the swing/extension targets (:267-276) */
     for (int l=0;l<4;l++) { tgtq[l]=se[l]; tgtq[4+2*l]=se[4+2*l]+se[5+2*l]/2; tgtq[5+2*l]=se[4+2*l]-se[5+2*l]/2; }
     const real *q=rb, *qd=rb+12, *acc=rb+24, *bp=rb+36, *bq=rb+39, *lv=rb+43, *av=rb+46, *tips=rb+49, *knees=rb+61;
@@ -395,8 +395,9 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     for (int i=0;i<3;i++) ob[k++]=(real)p->s_ang*oang[i];
     for (int i=0;i<12;i++) ob[k++]=(real)p->s_q*q[i];
     for (int i=0;i<12;i++) ob[k++]=(real)p->s_qd*qd[i];
-    for (int i=0;i<12;i++) ob[k++]=act[i];
-    for (int i=0;i<12;i++) ob[k++]=last_act[i];
+    if (!var2) { for (int i=0;i<12;i++) ob[k++]=act[i]; for (int i=0;i<12;i++) ob[k++]=last_act[i]; }
+    else { for (int i=0;i<12;i++) ob[k++]=(real)0.3*tgtq[i]; for (int i=0;i<12;i++) ob[k++]=(real)0.3*last_tgt[i]; }   /* position-control tasks:
+                                                   the joint position targets replace the actions (quadruped_pose_control_position_control.py:438-453) */
     if (var1) { for (int i=0;i<12;i++) ob[k++]=(real)0.3*tgtq[i]; for (int i=0;i<12;i++) ob[k++]=(real)0.3*last_tgt[i]; }   /* :432-455 */
     k=0;
     for (int i=0;i<3;i++) st[k++]=(real)p->s_pos*opos[i];
@@ -472,7 +473,7 @@ void lmo_task_eval(const lmo_params* p, int N, const real* readback, const real*
     c[3]=reset;
     rew[e]=total;
     tr[0]=rot_rew; tr[1]=trans; tr[2]=accp; tr[3]=rate; tr[4]=bonus; tr[5]=limp; tr[6]=fallp; tr[7]=(real)cgr; tr[8]=powp; tr[9]=terr; tr[10]=rdec;
-    if (var1 && p->cc_update_last_tgt) for (int i=0;i<12;i++) last_tgt[i]=tgtq[i];     /* :723-725, end of is_done */
+    if (pd && p->cc_update_last_tgt) for (int i=0;i<12;i++) last_tgt[i]=tgtq[i];     /* :723-725, end of is_done */
   }
 }
 
@@ -491,7 +492,7 @@ void lmo_reset(const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
     for (int i=0;i<12;i++) { ph[13+i]=(real)p->init_q[i]; ph[25+i]=0; tk[i]=0; tk[12+i]=0; tk[24+i]=(real)p->default_tip[i]; }
     for (int i=0;i<3;i++) { ph[i]=(real)p->init_base_pos[i]; ph[7+i]=0; ph[10+i]=0; ph[37+i]=(real)p->init_plate_pos[i]; ph[44+i]=0; ph[47+i]=0; }
     for (int i=0;i<4;i++) { ph[3+i]=(real)p->init_base_quat[i]; ph[40+i]=(real)p->init_plate_quat[i]; }
-    if (p->variant==1) {   /* :371-384 */
+    if (p->variant>=1) {   /* :371-384 */
       for (int i=0;i<12;i++) { tk[40+i]=(real)p->init_se[i]; tk[52+i]=(real)p->init_q[i]; }
       real qb[4]={(real)p->init_base_quat[0],-(real)p->init_base_quat[1],-(real)p->init_base_quat[2],-(real)p->init_base_quat[3]}, gc[4], qd4[4];
       if (p->mode==1) { qb[0]=1; qb[1]=qb[2]=qb[3]=0; }
@@ -519,6 +520,9 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
     for (int e=0;e<N;e++) { real* se=task+(size_t)e*LMO_TASK+40;
       for (int i=0;i<12;i++) { real v=se[i]+actions[(size_t)e*12+i]*(real)p->act_scale_se; if (v<(real)p->se_lo[i]) v=(real)p->se_lo[i]; if (v>(real)p->se_hi[i]) v=(real)p->se_hi[i]; se[i]=v; } }
     for (int s=0;s<p->substeps;s++) {
+      /* update_joint_states() runs after every in-task sub-step (…custom_controller.py:296-297), so the joint acceleration the reward sees
+         spans only the trailing acc_substeps (= controlFrequencyInv) sub-steps: remember the velocity they start from (robot.py:289-291) */
+      if (s==p->substeps-p->acc_substeps) for (int e=0;e<N;e++) for (int i=0;i<12;i++) task[(size_t)e*LMO_TASK+12+i]=phys[(size_t)e*LMO_PHYS+25+i];
       for (int e=0;e<N;e++) { const real* se=task+(size_t)e*LMO_TASK+40; const real* q=phys+(size_t)e*LMO_PHYS+13; real* tg=targets+(size_t)e*12; real qs[12];
         for (int l=0;l<4;l++) { qs[l]=se[l]; qs[4+2*l]=se[4+2*l]+se[5+2*l]/2; qs[5+2*l]=se[4+2*l]-se[5+2*l]/2; }
         /* tau = kp (q* - q) - kd qd  ==  kd (v* - qd)  with  v* = kp/kd (q* - q): the velocity-drive solver with a position-derived target */
@@ -532,12 +536,12 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
   for (int e=0;e<N;e++) {
     real* ph=phys+(size_t)e*LMO_PHYS; real* tk=task+(size_t)e*LMO_TASK; real* r=rb+(size_t)e*LMO_READBACK;
     for (int i=0;i<12;i++) { r[i]=ph[13+i]; r[12+i]=ph[25+i];
-      r[24+i]=(ph[25+i]-tk[12+i])/(real)p->ctrl_dt;   /* robot.py:290 */
+      r[24+i]=(ph[25+i]-tk[12+i])/((p->variant==0)?(real)p->ctrl_dt:(real)(p->dt*p->acc_substeps));   /* robot.py:290 */
       tk[12+i]=ph[25+i]; }
     const real* src=(p->mode==0)?ph:ph+37;
     for (int i=0;i<13;i++) r[36+i]=src[i];
     lmo_fk(m, p, ph, r+49, r+61); r[85]=r[86]=0;
-    for (int i=0;i<12;i++) r[87+i]=(p->variant==1)?tausum[(size_t)e*12+i]/(real)p->torque_div:0;
+    for (int i=0;i<12;i++) r[87+i]=(p->variant>=1)?tausum[(size_t)e*12+i]/(real)p->torque_div:0;
   }
   lmo_task_eval(p, N, rb, actions, task, cnt, obs, states, rew, terms);
   free(targets); free(rb); free(tausum);

@@ -102,7 +102,8 @@ typedef struct {
   /* ---- custom-controller task family (quadruped_pose_control_custom_controller.py:24-52,255-307,530-545):
    * actions integrate swing/extension position targets, the actuator is  tau = clamp(kp (q* - q) - kd qd, +-tau_max)
    * re-evaluated every sub-step (kd above is its damping gain), plus viscous joint damping */
-  int32_t variant;           /* 0 = velocity-drive tasks, 1 = custom-controller tasks */
+  int32_t variant;           /* 0 = velocity-drive tasks, 1 = custom-controller tasks, 2 = position-control tasks (same PD actuator and
+                                swing/extension actions; 64-wide observation whose last 24 entries are the scaled joint position targets; base reward) */
   int32_t num_obs;           /* 64 or 88 */
   double pd_kp;              /* 4.5 */
   double joint_damping;      /* 0.008 (0 for variant 0) */
@@ -112,7 +113,7 @@ typedef struct {
   double power_scale, target_err_scale, rot_dec_scale, rot_dec_thresh;
   int32_t cc_update_last_tgt;  /* 1: last_joint_position_targets follows the targets (loco, :723-725); 0: stays at its reset value
                                   (quadruped_manipulate_plate_custom_controller.py never updates it after :378) */
-  int32_t pad1;
+  int32_t acc_substeps;      /* variants 1/2: trailing sub-steps spanned by the joint acceleration (controlFrequencyInv; robot.py:289-291) */
 } lmo_params;
 
 /* per-env physical state, env-major */

@@ -49,7 +49,7 @@ class LmoParams(C.Structure):
         ("corner", (C.c_double * 3) * 4), ("ctrl_dt", C.c_double),
         ("variant", C.c_int32), ("num_obs", C.c_int32), ("pd_kp", C.c_double), ("joint_damping", C.c_double), ("act_scale_se", C.c_double),
         ("se_lo", C.c_double * 12), ("se_hi", C.c_double * 12), ("init_se", C.c_double * 12), ("torque_div", C.c_double),
-        ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("pad1", C.c_int32),
+        ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
     ]
 
 
@@ -92,7 +92,7 @@ def make_model(rm) -> LmoModel:
 def make_params(ep) -> LmoParams:
     p = LmoParams()
     for name, ctype in LmoParams._fields_:
-        if name in ("pad0", "pad1"):
+        if name in ("pad0",):
             continue
         val = getattr(ep, name)
         if isinstance(val, (list, tuple, np.ndarray)):

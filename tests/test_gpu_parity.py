@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from locomanipulationrl_amd.engine_config import loco_cc_params, loco_params, mani_cc_params, mani_params
+from locomanipulationrl_amd.engine_config import loco_cc_params, loco_params, loco_pc_params, mani_cc_params, mani_params, mani_pc_params
 
 pytestmark = pytest.mark.gpu
 
@@ -107,13 +107,31 @@ def test_contact_free_dynamics_tight(robot_model, engine_cls, oracle_cls, mode):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc"])
+def _cotrain_params(kind, N):
+    from locomanipulationrl_amd.utils.config import SimConfig, load_config
+    from locomanipulationrl_amd.utils.task_util import task_map
+    name = {"cotrain": "JointLocomanipulation", "cotrain_pc": "JointLocomanipulationPositionControl"}[kind]
+    cls = task_map()[name]
+    if kind == "cotrain":      # the committed file pins the goal to one orientation (joint_locomanipulation.py:61-66)
+        cls = type("PinnedGoal", (cls,), dict(min_roll=0.2, max_roll=0.2, min_pitch=0.2, max_pitch=0.2, min_yaw=0.785, max_yaw=0.785))
+    return cls(name=name, sim_config=SimConfig(load_config(name, num_envs=N)), env=None).engine_params()
+
+
+@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "cotrain", "cotrain_pc"])
 def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
+    """lm_task_eval (the kernel's task layer on supplied read-back states) against the reference's own Python for every task
+    family: velocity drive, custom controller, position control (single tasks: their `actions[:] = 0` line == action scale 0),
+    and the two co-training tasks (two parameter blocks, one launch)."""
     g = np.load(os.path.join(GOLDEN, f"task_{kind}.npz"))
-    ep = {"loco": loco_params, "mani": mani_params, "loco_cc": loco_cc_params, "mani_cc": mani_cc_params}[kind]()
-    cc = kind.endswith("_cc")
     T, N = g["rew"].shape
-    eng = engine_cls(robot_model, [ep], N)
+    if kind.startswith("cotrain"):
+        params = _cotrain_params(kind, N); split = N // 2
+    else:
+        params = [{"loco": loco_params, "mani": mani_params, "loco_cc": loco_cc_params, "mani_cc": mani_cc_params,
+                   "loco_pc": lambda: loco_pc_params(act_scale_se=0.0), "mani_pc": lambda: mani_pc_params(act_scale_se=0.0)}[kind]()]; split = None
+    ep = params[0]
+    cc = ep.variant >= 1; alias = "states" not in g.files or g["states"].shape[2] == 64
+    eng = engine_cls(robot_model, params, N, split_env=split)
     for t in range(T):
         eng.apply_resets(torch.as_tensor(g["goal_rand"][t], device="cuda"))
         o = outs(N, ep.num_obs)
@@ -122,7 +140,8 @@ def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
         torch.cuda.synchronize()
         obs, states, rew, resets, extras = [x.cpu().numpy() for x in o]
         assert np.abs(obs - np.clip(g["obs"][t], -5, 5)).max() < 2e-5
-        assert np.abs(states - np.clip(g["states"][t], -5, 5)).max() < 2e-5
+        if not alias:      # position-control and co-training tasks: states_buf aliases obs_buf (host mirror)
+            assert np.abs(states - np.clip(g["states"][t], -5, 5)).max() < 2e-5
         assert np.abs(eng.obs_buf.cpu().numpy() - g["obs"][t]).max() < 2e-5          # task.obs_buf is unclipped
         assert np.allclose(rew, g["rew"][t], rtol=2e-5, atol=1e-4)
         cnt = eng.get_cnt_env_major()
@@ -139,19 +158,23 @@ def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
         mine = dict(zip(["env/rewards/orientation_rew", "env/rewards/translation_penalty", "env/rewards/joint_acc_penalty",
                          "env/rewards/action_rate_penalty", "env/rewards/consecutive_successes_rew", "env/rewards/joint_limit_panelty",
                          "env/rewards/fall_penalty", "env/success_rate"], extras[:8]))
+        mine.update({"env/success_rate_loco": extras[8], "env/success_rate_mani": extras[9]})
         mine.update({"env/rewards/mechanical_power_penalty": extras[10], "env/rewards/position_target_error_penalty": extras[11],
                      "env/rewards/rot_dist_decreasing_reward": extras[12]})
         for k, v in ref.items():
             assert abs(mine[k] - v) < 2e-5 * max(1.0, abs(v)), (k, t)
         st = eng.stats_i64.cpu().numpy()
-        assert st[0] == g["num_successes"][t] and st[1] == g["num_resets"][t]
+        if "num_successes" in g.files:
+            assert st[0] == g["num_successes"][t] and st[1] == g["num_resets"][t]
+    if "counters" in g.files:      # all / loco / mani windows (joint_locomanipulation.py:846-855)
+        assert np.array_equal(eng.stats_i64.cpu().numpy()[:6], g["counters"])
     eng.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_full_step_parity_from_identical_states(robot_model, engine_cls, oracle_cls, mode):
-    """mode 2/3: the custom-controller variants (PD actuator on swing/extension targets, 88-wide observation)."""
-    ep = [loco_params, mani_params, loco_cc_params, mani_cc_params][mode]()
+    """mode 2/3: the custom-controller variants (PD actuator on swing/extension targets, 88-wide observation); 4/5: position control."""
+    ep = [loco_params, mani_params, loco_cc_params, mani_cc_params, loco_pc_params, mani_pc_params][mode]()
     N = 256; o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N, seed=42)
     rng = np.random.default_rng(5)
     phys, task, cnt = o.new_state(N)
@@ -176,8 +199,9 @@ def test_full_step_parity_from_identical_states(robot_model, engine_cls, oracle_
         assert np.array_equal(c2[:, 4], cnt[:, 4]) and np.array_equal(c2[:, 5], cnt[:, 5])
         gt = eng.get_task_env_major()
         assert np.abs(gt[:, 36:40] - task[:, 36:40]).max() < 1e-6     # same goals: the hash RNG is bit-exact
-        if ep.variant == 1:
+        if ep.variant >= 1:
             assert np.abs(gt[:, 40:64] - task[:, 40:64]).max() < 2e-6   # swing/extension targets and last joint targets
+        if ep.variant == 1:
             assert abs(gex[10] - terms[:, 8].mean()) < 5e-3 * max(1.0, abs(terms[:, 8].mean())) and abs(gex[11] - terms[:, 9].mean()) < 1e-4
     assert bad_total <= 0.01 * 5 * N, bad_total
     eng.close()
@@ -260,7 +284,9 @@ def test_cotrain_two_task_engine(robot_model, engine_cls, oracle_cls):
 
 @pytest.mark.parametrize("task_name", ["QuadrupedPoseControl", "QuadrupedManipulatePlate", "JointLocomanipulation",
                                        "QuadrupedPoseControlVertical", "QuadrupedManipulatePlateVertical", "JointLocomanipulationVertical",
-                                       "QuadrupedPoseControlCustomController", "QuadrupedManipulatePlateCustomController"])
+                                       "QuadrupedPoseControlCustomController", "QuadrupedManipulatePlateCustomController",
+                                       "QuadrupedPoseControlPositionControl", "QuadrupedManipulatePlatePositionControl",
+                                       "JointLocomanipulationPositionControl"])
 def test_every_task_config_two_step_parity(engine_cls, oracle_cls, task_name):
     """All six task families of the path (horizontal / vertical x loco / mani / co-train), parameters exactly as the task
     classes build them: reset step + one random-action step against the oracle."""

@@ -80,17 +80,24 @@ def test_staged_api_equals_fused_step():
 
 
 @pytest.mark.parametrize("task", ["QuadrupedManipulatePlate", "QuadrupedPoseControlVertical", "QuadrupedManipulatePlateVertical",
-                                  "QuadrupedPoseControlCustomController", "QuadrupedManipulatePlateCustomController"])
+                                  "QuadrupedPoseControlCustomController", "QuadrupedManipulatePlateCustomController",
+                                  "QuadrupedPoseControlPositionControl", "QuadrupedManipulatePlatePositionControl"])
 def test_other_tasks_run(task):
     env = make(task, 16)
     o = env.reset()
-    cc = "CustomController" in task
+    cc = "CustomController" in task; pc = "PositionControl" in task
     assert o["obs"].shape == (16, 88 if cc else 64) and env.observation_space.shape == ((88,) if cc else (64,))
     g = torch.Generator().manual_seed(1)
     for t in range(30):
         o, rew, resets, _ = env.step(torch.rand(16, 12, generator=g) * 2 - 1)
         assert torch.isfinite(o["obs"]).all() and torch.isfinite(rew).all()
     assert float(rew.min()) > -50
+    if pc:
+        assert env.num_states == 64 and torch.equal(o["obs"], o["states"])          # …position_control.py:455
+        tgt = env._task.current_joint_position_targets_se
+        assert tgt.shape == (16, 12) and float((tgt - torch.tensor(env._task.init_joint_pos_swing_ext)).abs().max()) > 0.05
+        with pytest.raises(NotImplementedError):
+            env._task.pre_physics_step(torch.zeros(16, 12))
     if cc:
         _, _, _, extras = env.step(torch.zeros(16, 12))
         assert "env/rewards/mechanical_power_penalty" in extras and float(extras["env/rewards/mechanical_power_penalty"]) <= 0
@@ -98,8 +105,9 @@ def test_other_tasks_run(task):
             env._task.pre_physics_step(torch.zeros(16, 12))
 
 
-def test_cotrain_layout():
-    env = make("JointLocomanipulation", 32)
+@pytest.mark.parametrize("name", ["JointLocomanipulation", "JointLocomanipulationPositionControl"])
+def test_cotrain_layout(name):
+    env = make(name, 32)
     assert env.num_states == 64
     o = env.reset()
     assert o["states"].shape == (32, 64) and torch.equal(o["obs"], o["states"])          # joint_locomanipulation.py:548
@@ -108,10 +116,11 @@ def test_cotrain_layout():
     t = env._task
     assert t.robot_locomotion.joint_positions.shape == (16, 12) and t.robot_manipulation.joint_positions.shape == (16, 12)
     # loco half: base at z~0.18 above ground; mani half: plate around z 0.68 over the inverted robot at 0.5
-    assert abs(float(t.engine.state[2, :16].mean()) - 0.18) < 0.03
-    assert abs(float(t.engine.state[39, 16:].mean()) - 0.68) < 0.03
+    pc = "PositionControl" in name      # …position_control.py:142,214: base at 0.14, plate dropped from 0.64
+    assert abs(float(t.engine.state[2, :16].mean()) - (0.14 if pc else 0.18)) < 0.03
+    assert abs(float(t.engine.state[39, 16:].mean()) - (0.64 if pc else 0.68)) < 0.03
     with pytest.raises(AssertionError):
-        make("JointLocomanipulation", 40)
+        make(name, 40)
 
 
 def test_torch_goal_sampler_and_seed():

@@ -173,8 +173,14 @@ def _rand_unit_quat(g, n, small=None):
 
 
 def make_task(kind, N):
-    cc = kind.endswith("_cc")
-    if kind == "loco_cc":
+    cc = kind.endswith("_cc"); pc = kind.endswith("_pc")
+    if kind == "loco_pc":
+        from tasks.quadruped_pose_control_tasks.quadruped_pose_control_position_control import QuadrupedPoseControlPositionControl as T
+        mangle = "_QuadrupedPoseControlPositionControl"
+    elif kind == "mani_pc":
+        from tasks.quadruped_manipulate_plate.quadruped_manipulate_plate_position_control import QuadrupedManipulatePlatePositionControl as T
+        mangle = "_QuadrupedManipulatePlatePositionControl"
+    elif kind == "loco_cc":
         from tasks.quadruped_pose_control_tasks.quadruped_pose_control_custom_controller import QuadrupedPoseControlCustomController as T
         mangle = "_QuadrupedPoseControlCustomController"
     elif kind == "mani_cc":
@@ -189,12 +195,12 @@ def make_task(kind, N):
     from utils.math import transform_vectors
     t = object.__new__(T)
     dev = "cpu"
-    t._device, t._num_envs, t._num_actions, t._num_observations, t._num_states = dev, N, 12, (88 if cc else 64), 93
-    t._max_episode_length = 500 if cc else 300
+    t._device, t._num_envs, t._num_actions, t._num_observations, t._num_states = dev, N, 12, (88 if cc else 64), (64 if pc else 93)
+    t._max_episode_length = {"loco_pc": 500, "mani_pc": 450}.get(kind, 500 if cc else 300)
     t._env = types.SimpleNamespace(_world=None)
     t._dr_randomizer = FakeDR()
     z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
-    t.obs_buf, t.states_buf, t.rew_buf = z(N, 88 if cc else 64), z(N, 93), z(N)
+    t.obs_buf, t.states_buf, t.rew_buf = z(N, 88 if cc else 64), z(N, 64 if pc else 93), z(N)
     t.reset_buf = torch.ones(N, dtype=torch.long); t.progress_buf = z(N, dt=torch.long); t.extras = {}
     t.last_actions, t.current_actions = z(N, 12), z(N, 12)
     t.last_base_tip_positions = z(N, 4, 3)
@@ -223,7 +229,18 @@ def make_task(kind, N):
             t.joint_positions_loco = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_loco = torch.zeros(N, 12)
         else:
             t.joint_positions_mani = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_mani = torch.zeros(N, 12)
-    if kind in ("loco", "loco_cc"):
+    if pc:   # position-control state (…_position_control.py:181-199)
+        t.current_joint_position_targets = init_q[:12].repeat(N, 1).clone()
+        t.last_joint_position_targets = t.current_joint_position_targets.clone()
+        t.current_joint_position_targets_se = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.57, 1.05, 1.57, 1.05, 1.57, 1.05, -1.57, 1.05]).repeat(N, 1)
+        t.joint_position_target_se_upper = torch.tensor(T.max_joint_pos_swing_ext, dtype=torch.float32)
+        t.joint_position_target_se_lower = torch.tensor(T.min_joint_pos_swing_ext, dtype=torch.float32)
+        if kind == "loco_pc":
+            t.joint_positions_loco = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_loco = torch.zeros(N, 12)
+        else:
+            t.joint_positions_mani = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_mani = torch.zeros(N, 12)
+    zfix = 0.3 if kind == "mani_pc" else 0.0
+    if kind in ("loco", "loco_cc", "loco_pc"):
         t.robot_locomotion = FakeRobot(N)
         t.pose_indicator_loco = FakeObj(N)
         t.default_joint_positions_loco = init_q.repeat((N, 1))
@@ -234,9 +251,9 @@ def make_task(kind, N):
         t.robot_manipulation = FakeRobot(N)
         t.pose_indicator_mani = FakeObj(N); t.obj = FakeObj(N)
         t.default_joint_positions_mani = init_q.repeat((N, 1))
-        t.default_robot_positions_mani = torch.tensor([0.0, 0.0, 0.0]).repeat((N, 1))
+        t.default_robot_positions_mani = torch.tensor([0.0, 0.0, zfix]).repeat((N, 1))
         t.default_robot_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
-        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.18 if cc else 0.14]).repeat((N, 1))
+        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.44 if pc else (0.18 if cc else 0.14)]).repeat((N, 1))
         t.default_obj_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
         t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
         setattr(t, mangle + "__corner_pos_world",
@@ -250,7 +267,8 @@ def gen_task(kind, N=32, T=26, seed=7):
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
     t = make_task(kind, N)
-    cc = kind.endswith("_cc"); base_kind = kind[:4]
+    cc = kind.endswith("_cc"); pc = kind.endswith("_pc"); base_kind = kind[:4]
+    zfix = 0.3 if kind == "mani_pc" else 0.0
     robot = t.robot_locomotion if base_kind == "loco" else t.robot_manipulation
     init_q = torch.tensor([-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]) if cc else \
         torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
@@ -267,9 +285,7 @@ def gen_task(kind, N=32, T=26, seed=7):
             st = torch.get_rng_state()
             goal_rand[ids] = torch.rand((len(ids), 3))
             torch.set_rng_state(st)
-        if cc and step > 0:
-            pass
-        t.pre_physics_step(actions)
+        t.pre_physics_step(actions.clone())      # (the position-control files zero their argument in place, :261)
         # ---- synthetic read-back state, spread across the thresholds of Appendix D
         q = init_q.repeat(N, 1) + 0.25 * torch.randn(N, 12, generator=g)
         q[0:4, 5] = q[0:4, 4] - torch.tensor([0.40, 0.39, 2.55, 2.62])        # |dof3-dof2| around penalty/reset windows
@@ -307,6 +323,8 @@ def gen_task(kind, N=32, T=26, seed=7):
         knees[track, :, 2] = 0.1 if base_kind == "loco" else 0.02
         robot.joint_positions, robot.joint_velocities, robot.joint_accelerations = q, qd, acc
         robot.tip_positions, robot.knee_positions = tips, knees
+        if zfix:   # the fixed robot (and everything measured relative to it) sits at z = zfix in the world
+            pos[:, 2] += zfix; tips[:, :, 2] += zfix; knees[:, :, 2] += zfix
         if base_kind == "loco":
             robot.base_positions, robot.base_quaternions = pos, quat
             robot.base_linear_velocities, robot.base_angular_velocities = lin, ang
@@ -316,10 +334,12 @@ def gen_task(kind, N=32, T=26, seed=7):
         t.progress_buf[:] += 1
         t.get_observations(); t.calculate_metrics(); t.is_done()
         rb = torch.cat((q, qd, acc, pos, quat, lin, ang, tips.reshape(N, 12), knees.reshape(N, 24), torch.zeros(N, 2)), dim=-1)
-        if cc:
+        if cc or pc:
             rb = torch.cat((rb, t.torque), dim=-1)
             rec["torque"].append(t.torque.clone()); rec["se"].append(t.current_joint_position_targets_se.clone())
-            rec["last_targets"].append(t.last_joint_position_targets.clone()); rec["last_rot_dist"].append(t.last_rot_dist.clone())
+            rec["last_targets"].append(t.last_joint_position_targets.clone())
+            if cc:
+                rec["last_rot_dist"].append(t.last_rot_dist.clone())
         if extras_keys is None:
             extras_keys = sorted(t.extras.keys())
         rec["readback"].append(rb); rec["actions"].append(actions); rec["goal_rand"].append(goal_rand)
@@ -335,6 +355,154 @@ def gen_task(kind, N=32, T=26, seed=7):
         rec["joint_reset"].append((t.joint1_pos_reset + t.joint23_pos_reset).clone())
     out = {k: torch.stack(v).numpy() for k, v in rec.items() if len(v) > 0}
     out["extras_keys"] = np.array(extras_keys)
+    return out
+
+
+# ----------------------------------------------------------------------------- co-training tasks (a14, f-1)
+def make_cotrain_task(kind, N):
+    """JointLocomanipulation / JointLocomanipulationPositionControl on fakes: envs [0, N/2) locomotion, [N/2, N) manipulation."""
+    pc = kind == "cotrain_pc"
+    if pc:
+        from tasks.joint_train_locomanipulation.joint_locomanipulation_position_control import JointLocomanipulationPositionControl as T
+        mangle = "_JointLocomanipulationPositionControl"
+    else:
+        from tasks.joint_train_locomanipulation.joint_locomanipulation import JointLocomanipulation as T
+        mangle = "_JointLocomanipulation"
+    from utils.math import transform_vectors
+    h = N // 2
+    t = object.__new__(T)
+    t.RECORD_JOINT = False          # the class default dumps joint trajectories to an absolute path of the authors' machine and exits
+    t._device, t._num_envs, t._num_actions, t._num_observations, t._num_states = "cpu", N, 12, 64, 64
+    t._single_task_num_envs = h
+    t._max_episode_length = 300
+    t._env = types.SimpleNamespace(_world=None)
+    t._dr_randomizer = FakeDR()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
+    t.obs_buf, t.states_buf, t.rew_buf = z(N, 64), z(N, 64), z(N)
+    t.reset_buf = torch.ones(N, dtype=torch.long); t.progress_buf = z(N, dt=torch.long); t.extras = {}
+    t.last_actions, t.current_actions = z(N, 12), z(N, 12)
+    t.last_base_tip_positions = z(N, 4, 3)
+    t.default_base_tip_positions = torch.tensor([[-0.0937, 0.1223, -0.1774], [0.0937, 0.1408, -0.1773],
+                                                 [-0.0937, -0.1408, -0.1773], [0.0937, -0.1223, -0.1774]]).repeat((N, 1, 1))
+    corner = torch.cat((torch.tensor([0.075, 0.1835, -0.04]).repeat(h, 1), torch.tensor([-0.075, 0.1835, -0.04]).repeat(h, 1),
+                        torch.tensor([0.075, -0.1835, -0.04]).repeat(h, 1), torch.tensor([-0.075, -0.1835, -0.04]).repeat(h, 1)),
+                       dim=-1).view(h, 4, 3).to(torch.float32)
+    setattr(t, mangle + "__corner_pos_robot", corner)
+    t.goal_quaternions = z(N, 4)
+    t.successes, t.consecutive_successes, t.goal_reset_buf = z(N, dt=torch.long), z(N, dt=torch.long), z(N, dt=torch.long)
+    for sfx in ("", "_loco", "_mani"):
+        setattr(t, "max_reset_counts" + sfx, torch.tensor(2048, dtype=torch.long))
+        setattr(t, "num_successes" + sfx, torch.tensor(0, dtype=torch.long)); setattr(t, "num_resets" + sfx, torch.tensor(0, dtype=torch.long))
+        setattr(t, "success_rate" + sfx, torch.tensor(0.0))
+    t.randomization_buf = z(N, dt=torch.long)
+    init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4)
+    t.robot_locomotion, t.robot_manipulation = FakeRobot(h), FakeRobot(h)
+    t.pose_indicator_loco, t.pose_indicator_mani, t.obj = FakeObj(h), FakeObj(h), FakeObj(h)
+    t.default_joint_positions_loco = init_q.repeat((h, 1)); t.default_joint_positions_mani = init_q.repeat((h, 1))
+    t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.14]).repeat((h, 1))
+    t.default_robot_quaternions_loco = torch.tensor([1.0, 0, 0, 0]).repeat((h, 1))
+    t.default_robot_positions_mani = torch.tensor([0.0, 0.0, 0.5]).repeat((h, 1))           # joint_locomanipulation.py:139
+    t.default_robot_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((h, 1))
+    t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.64 if pc else 0.68]).repeat((h, 1))
+    t.default_obj_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((h, 1))
+    t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((h, 1))
+    t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.8]]).repeat((h, 1))
+    setattr(t, mangle + "__corner_pos_world", transform_vectors(t.default_robot_quaternions_mani, t.default_robot_positions_mani, corner, "cpu"))
+    if pc:   # joint_locomanipulation_position_control.py:218-243
+        t.joint_positions_combined = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_combined = z(N, 12)
+        t.default_joint_positions_combined = init_q[:12].repeat(N, 1).clone()
+        t.current_joint_position_targets = init_q[:12].repeat(N, 1).clone()
+        t.last_joint_position_targets = t.current_joint_position_targets.clone()
+        t.current_joint_position_targets_se = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.57, 1.05, 1.57, 1.05, 1.57, 1.05, -1.57, 1.05]).repeat(N, 1)
+        t.joint_position_target_se_upper = torch.tensor(T.max_joint_pos_swing_ext, dtype=torch.float32)
+        t.joint_position_target_se_lower = torch.tensor(T.min_joint_pos_swing_ext, dtype=torch.float32)
+    return t
+
+
+def _synth_half(g, mani, n, init_q, goal, zfix):
+    """Synthetic read-back state of one half (n envs), straddling the thresholds of Appendix D; envs n-6.. track their goal."""
+    from omni.isaac.core.utils.torch.rotations import quat_conjugate, quat_mul
+    q = init_q.repeat(n, 1) + 0.25 * torch.randn(n, 12, generator=g)
+    q[0:2, 5] = q[0:2, 4] - torch.tensor([0.40, 2.62]); q[2:4, 0] = torch.tensor([-2.40, 0.90]); q[4:6, 1] = torch.tensor([2.40, -0.90])
+    qd = 2.0 * torch.randn(n, 12, generator=g); acc = 20.0 * torch.randn(n, 12, generator=g)
+    pos = torch.cat((0.05 * torch.randn(n, 2, generator=g), 0.13 + 0.02 * torch.randn(n, 1, generator=g)), dim=-1)
+    quat = _rand_unit_quat(g, n, small=0.25)
+    lin = 0.3 * torch.randn(n, 3, generator=g); ang = 1.0 * torch.randn(n, 3, generator=g)
+    tips = 0.15 * torch.randn(n, 4, 3, generator=g)
+    kz = 0.03 if mani else 0.10
+    knees = torch.cat((0.15 * torch.randn(n, 8, 2, generator=g), kz + 0.03 * torch.randn(n, 8, 1, generator=g)), dim=-1)
+    flip = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    if mani:
+        quat = quat_mul(_rand_unit_quat(g, n, small=0.2), flip.repeat(n, 1))
+        pos[6, 2] = 0.051; pos[7, 2] = 0.049; pos[8, 2] = -0.01
+    else:
+        pos[6, 2] = 0.049; pos[7, 2] = 0.051
+        quat[8] = flip
+        knees[9, 3, 2] = 0.0399; knees[10, 3, 2] = 0.0401
+    track = torch.arange(n - 6, n)
+    small = _rand_unit_quat(g, len(track), small=0.02)
+    if mani:
+        quat[track] = quat_mul(flip.repeat(len(track), 1), quat_mul(small, goal[track]))
+    else:
+        quat[track] = quat_conjugate(quat_mul(small, goal[track]))
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    pos[track] = torch.tensor([0.0, 0.0, 0.13]); q[track] = init_q
+    knees[track, :, 2] = 0.02 if mani else 0.1
+    knees[track, :, :2] *= 0.2          # keep the tracking envs' knees clear of the tilted plate so they reach the bonus
+    pos[:, 2] += zfix; tips[:, :, 2] += zfix; knees[:, :, 2] += zfix
+    return q, qd, acc, pos, quat, lin, ang, tips, knees
+
+
+def gen_cotrain(kind, N=32, T=30, seed=13):
+    """The co-training tasks through T post-physics evaluations (same protocol as gen_task; both halves in one call)."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    t = make_cotrain_task(kind, N); h = N // 2; pc = kind == "cotrain_pc"
+    init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
+    rec = {k: [] for k in ("readback", "actions", "goal_rand", "obs", "rew", "reset_buf", "goal_reset_buf", "successes", "consecutive_successes",
+                           "progress_buf", "last_actions", "last_base_tip", "goal_quaternions", "extras", "joint_reset", "se", "last_targets", "torque")}
+    extras_keys = None
+    for step in range(T):
+        actions = (torch.rand(N, 12, generator=g) * 2 - 1).clamp(-1, 1)
+        # reset_idx draws the locomotion goals first, then the manipulation goals (joint_locomanipulation.py:319-334)
+        ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        goal_rand = torch.zeros(N, 3)
+        if len(ids) > 0:
+            st = torch.get_rng_state()
+            il, im = ids[ids < h], ids[ids >= h]
+            goal_rand[il] = torch.rand((len(il), 3)); goal_rand[im] = torch.rand((len(im), 3))
+            torch.set_rng_state(st)
+        t.pre_physics_step(actions.clone())
+        ql, qdl, accl, posl, quatl, linl, angl, tipsl, kneesl = _synth_half(g, False, h, init_q, t.goal_quaternions[:h], 0.0)
+        qm, qdm, accm, posm, quatm, linm, angm, tipsm, kneesm = _synth_half(g, True, h, init_q, t.goal_quaternions[h:], 0.5)
+        rl, rm = t.robot_locomotion, t.robot_manipulation
+        rl.joint_positions, rl.joint_velocities, rl.joint_accelerations, rl.tip_positions, rl.knee_positions = ql, qdl, accl, tipsl, kneesl
+        rl.base_positions, rl.base_quaternions, rl.base_linear_velocities, rl.base_angular_velocities = posl, quatl, linl, angl
+        rm.joint_positions, rm.joint_velocities, rm.joint_accelerations, rm.tip_positions, rm.knee_positions = qm, qdm, accm, tipsm, kneesm
+        t.obj.pos, t.obj.quat, t.obj.lin, t.obj.ang = posm, quatm, linm, angm
+        t.progress_buf[:] += 1
+        t.get_observations(); t.calculate_metrics(); t.is_done()
+        cat = lambda a, b: torch.cat((a, b), dim=0)
+        rb = torch.cat((cat(ql, qm), cat(qdl, qdm), cat(accl, accm), cat(posl, posm), cat(quatl, quatm), cat(linl, linm), cat(angl, angm),
+                        cat(tipsl, tipsm).reshape(N, 12), cat(kneesl, kneesm).reshape(N, 24), torch.zeros(N, 2),
+                        t.torque if pc else torch.zeros(N, 12)), dim=-1)
+        if pc:
+            rec["se"].append(t.current_joint_position_targets_se.clone()); rec["last_targets"].append(t.last_joint_position_targets.clone())
+            rec["torque"].append(t.torque.clone())
+        if extras_keys is None:
+            extras_keys = sorted(t.extras.keys())
+        rec["readback"].append(rb); rec["actions"].append(actions); rec["goal_rand"].append(goal_rand)
+        rec["obs"].append(t.obs_buf.clone()); rec["rew"].append(t.rew_buf.clone())
+        rec["reset_buf"].append(t.reset_buf.clone()); rec["goal_reset_buf"].append(t.goal_reset_buf.clone())
+        rec["successes"].append(t.successes.clone()); rec["consecutive_successes"].append(t.consecutive_successes.clone())
+        rec["progress_buf"].append(t.progress_buf.clone()); rec["last_actions"].append(t.last_actions.clone())
+        rec["last_base_tip"].append(t.last_base_tip_positions.reshape(N, 12).clone())
+        rec["goal_quaternions"].append(t.goal_quaternions.clone())
+        rec["extras"].append(torch.stack([torch.as_tensor(t.extras[k], dtype=torch.float32) for k in extras_keys]))
+        rec["joint_reset"].append((t.joint1_pos_reset + t.joint23_pos_reset).clone())
+    out = {k: torch.stack(v).numpy() for k, v in rec.items() if len(v) > 0}
+    out["extras_keys"] = np.array(extras_keys)
+    out["counters"] = np.array([int(getattr(t, n + s)) for s in ("", "_loco", "_mani") for n in ("num_successes", "num_resets")])
     return out
 
 
@@ -426,12 +594,17 @@ def main():
     _install_placeholders()
     sys.path[:0] = [REF_RL, os.path.dirname(REF_RL)]
     os.makedirs(OUT, exist_ok=True)
-    for kind in ("loco", "mani", "loco_cc", "mani_cc"):
-        d = gen_task(kind, T=32 if kind.endswith("_cc") else 26)
+    for kind in ("loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc"):
+        d = gen_task(kind, T=26 if kind in ("loco", "mani") else 32)
         np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
         print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "states", "rew", "extras")},
               "resets/step", d["reset_buf"].sum(1)[:8], "max consec", d["consecutive_successes"].max(),
               "bonus steps", int((d["rew"] > 300).sum()))
+    for kind in ("cotrain", "cotrain_pc"):
+        d = gen_cotrain(kind)
+        np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
+        print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "rew", "extras")}, "resets/step", d["reset_buf"].sum(1)[:8],
+              "max consec", d["consecutive_successes"].max(), "bonus steps", int((d["rew"] > 300).sum()), "counters", d["counters"])
     np.savez_compressed(os.path.join(OUT, "math.npz"), **gen_math())
     np.savez_compressed(os.path.join(OUT, "take_action.npz"), **gen_take_action())
     np.savez_compressed(os.path.join(OUT, "gnn.npz"), **gen_gnn())
