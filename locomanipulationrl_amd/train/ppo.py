@@ -57,10 +57,12 @@ class PPO:
         self.gamma, self.lam, self.lr, self.kl_thr = gamma, lam, lr, kl_threshold
         self.gclip, self.rclip, self.vclip, self.vscale, self.escale = grad_norm_clip, ratio_clip, value_clip, value_loss_scale, entropy_loss_scale
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
-        self.obs_scaler = RunningStandardScaler(64, self.dev); self.val_scaler = RunningStandardScaler(1, self.dev)
-        self.hip = hip_inference and hasattr(model, "act_inference") and torch.cuda.is_available()
+        self.n_obs = int(env.observation_space.shape[0])          # 88 for the custom-controller tasks
+        self.obs_scaler = RunningStandardScaler(self.n_obs, self.dev); self.val_scaler = RunningStandardScaler(1, self.dev)
+        # the MFMA forward kernels take the 64-wide observation; wider observations use the torch modules for rollouts too
+        self.hip = hip_inference and hasattr(model, "act_inference") and torch.cuda.is_available() and self.n_obs == 64
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=self.dev, dtype=dt)
-        self.b_obs, self.b_act, self.b_logp = z(self.T, self.N, 64), z(self.T, self.N, 12), z(self.T, self.N)
+        self.b_obs, self.b_act, self.b_logp = z(self.T, self.N, self.n_obs), z(self.T, self.N, 12), z(self.T, self.N)
         self.b_val, self.b_rew, self.b_done = z(self.T, self.N), z(self.T, self.N), z(self.T, self.N)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -95,7 +97,7 @@ class PPO:
         ret, adv = D.compute_gae(self.b_rew, self.b_val, self.b_done, last_value, self.gamma, self.lam)
         g_ret, g_adv = D.all_gather_rollout(ret, adv)                 # RCCL all-gather over xGMI when world > 1
         adv = (adv - g_adv.mean()) / (g_adv.std() + 1e-8)             # global advantage normalisation
-        obs, act = self.b_obs.reshape(-1, 64), self.b_act.reshape(-1, 12)
+        obs, act = self.b_obs.reshape(-1, self.n_obs), self.b_act.reshape(-1, 12)
         old_logp, old_val = self.b_logp.reshape(-1), self.b_val.reshape(-1)
         ret, adv = ret.reshape(-1), adv.reshape(-1)
         self.obs_scaler.update(obs); self.val_scaler.update(ret.unsqueeze(-1))      # preprocessors train on the first epoch's data

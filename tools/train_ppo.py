@@ -25,7 +25,7 @@ def main():
         model = GraphPolicy().to(f"cuda:{local}"); hip = True
     else:
         from locomanipulationrl_amd.policies.mlp_model import SharedMLP
-        model = SharedMLP().to(f"cuda:{local}"); hip = True
+        model = SharedMLP(num_observations=env.observation_space.shape[0]).to(f"cuda:{local}"); hip = True
     if world > 1:
         for p in model.parameters(): torch.distributed.broadcast(p.data, 0)
     ppo = PPO(env, model, hip_inference=hip)
