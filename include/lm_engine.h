@@ -44,6 +44,24 @@ extern "C" {
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
  * sources in the reference are cited there. */
+/* Domain randomisation.  One channel = one entry of the YAML block cfg/task/QuadrupedPoseControl.yaml:116-173
+ * (operation / distribution / distribution_parameters [/ frequency_interval]).  Observation and action noise follow
+ * utils/domain_randomization/randomize.py:212-306 (wrapper call sites vec_env_rlgames.py:56-58,70-72); the physics attributes are
+ * sampled per env inside lm_step (the reference delegates them to omni.replicator.isaac; semantics in DESIGN.md 3.6). */
+#define LM_DR_CHANNELS 8
+enum { LM_DR_OBS_RESET = 0, LM_DR_OBS_INTERVAL = 1, LM_DR_ACT_RESET = 2, LM_DR_ACT_INTERVAL = 3,
+       LM_DR_GRAVITY = 4, LM_DR_BASE_FORCE = 5, LM_DR_MAX_EFFORT = 6, LM_DR_MAX_VELOCITY = 7 };
+enum { LM_DR_ADDITIVE = 0, LM_DR_SCALING = 1, LM_DR_DIRECT = 2 };
+enum { LM_DR_GAUSSIAN = 0, LM_DR_UNIFORM = 1, LM_DR_LOGUNIFORM = 2 };
+typedef struct lm_dr_channel {
+  int32_t enabled;
+  int32_t operation;       /* LM_DR_ADDITIVE / SCALING / DIRECT */
+  int32_t distribution;    /* LM_DR_GAUSSIAN / UNIFORM / LOGUNIFORM */
+  int32_t interval;        /* frequency_interval of an on_interval entry (>= 1); 0 = on_reset entry */
+  float p0[3], p1[3];      /* distribution_parameters: mean / std or low / high (one pair per component for gravity and force) */
+} lm_dr_channel;
+#define LM_DR_CNT_ROWS 5   /* int64 [row][N]: observation noise counter, action noise counter, dr_step, randomization_buf, dr_reset_key */
+
 typedef struct lm_params {
   float dt, kd, tau_max, act_scale, mu, tip_radius, baumgarte, max_depen_vel, max_joint_vel, gravity;
   int32_t substeps, pgs_iters, mode;
@@ -68,6 +86,9 @@ typedef struct lm_params {
   float torque_div, power_scale, target_err_scale, rot_dec_scale, rot_dec_thresh;
   int32_t cc_update_last_tgt;
   int32_t acc_substeps;      /* variants 1/2: trailing sub-steps the joint acceleration spans (controlFrequencyInv; robot.py:289-291) */
+  int32_t dr_enabled;        /* domain_randomization.randomize */
+  int32_t dr_min_frequency;  /* domain_randomization.min_frequency: gate of the on_reset physics attributes (quadruped_pose_control.py:224-228) */
+  lm_dr_channel dr[LM_DR_CHANNELS];
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */
@@ -86,7 +107,9 @@ typedef enum {
   LM_PTR_REW_BUF = 4,   /* float [N]      task.rew_buf                               */
   LM_PTR_EXTRAS = 5,    /* float [LM_NUM_EXTRAS]  reward-term means + success rates     */
   LM_PTR_STATS = 6,     /* int64 [6] {num_successes, num_resets} x {all, task 0, task 1}; float [3] rates at byte 48 */
-  LM_PTR_TERMS = 7      /* float [LM_TERM_ROWS][N]  per-env reward terms of the last step */
+  LM_PTR_TERMS = 7,     /* float [LM_TERM_ROWS][N]  per-env reward terms of the last step */
+  LM_PTR_DR_CNT = 8,    /* int64 [LM_DR_CNT_ROWS][N]  domain-randomisation counters */
+  LM_PTR_DR_PHYS = 9    /* float [30][N]  attributes sampled for the last step: max efforts 12, max joint velocities 12, gravity 3, base force 3 */
 } lm_ptr_kind;
 
 /* Create an engine for n_envs environments on the current HIP device.
@@ -106,7 +129,9 @@ int lm_destroy(lm_engine* h);
  *   goal_rand   device float [N][3] uniforms for goal sampling, or NULL for the in-kernel hash RNG
  *   out_*       device buffers receiving clipped copies for the caller (any may be NULL):
  *               obs [N][lm_num_obs], states [N][93], rew [N], resets int64 [N], extras float [LM_NUM_EXTRAS]
- *   stream      hipStream_t (void* here so the header needs no HIP include) */
+ *   stream      hipStream_t (void* here so the header needs no HIP include)
+ * With params.dr_enabled the same launch also applies the action noise (before the clamp), samples this step's physics attributes
+ * and adds the observation noise (obs_buf and out_obs); the staged entry points below refuse a randomised engine. */
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states,
             float* out_rew, int64_t* out_resets, float* out_extras, void* stream);
 

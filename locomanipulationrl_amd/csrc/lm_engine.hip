@@ -47,7 +47,7 @@ struct lm_engine {
   uint32_t seed;
   lm_params* d_params;     // [2]
   float* d_table;
-  float* d_state; int64_t* d_cnt;
+  float* d_state; int64_t* d_cnt; int64_t* d_drc; float* d_dr_phys; int dr_enabled;
   float *d_obs, *d_states, *d_rew, *d_extras, *d_terms, *d_partials;
   char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48
   lm_params h_params[2];
@@ -78,6 +78,26 @@ LM_DEV void lm_sincos(float x, float* s, float* c) {
   *s = (k & 2) ? -ss : ss;
   *c = ((k + 1) & 2) ? -cc : cc;
 }
+
+// ---- domain randomisation: counter-based samples, same bits as oracle lmo_dr_sample up to fp32 rounding of log / cos
+LM_DEV float dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, uint32_t idx, int dist, float p0, float p1) {
+  uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ mix32(stream * 0x27D4EB2FU + 0x632BE5ABU));
+  uint32_t r1 = mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
+  if (dist == LM_DR_GAUSSIAN) { float sn, cs; lm_sincos(6.283185307179586f * u2, &sn, &cs); return p0 + p1 * (sqrtf(-2.0f * logf(u1)) * cs); }
+  if (dist == LM_DR_UNIFORM) return p0 + (p1 - p0) * u2;
+  return expf(logf(p0) + (logf(p1) - logf(p0)) * u2);
+}
+LM_DEV float dr_apply(int op, float x, float n) { return op == LM_DR_ADDITIVE ? x + n : (op == LM_DR_SCALING ? x * n : n); }
+// one randomised physics attribute: on_interval entries are redrawn every `interval` control steps, on_reset entries at the env's
+// last gated reset (reset_key 0 = never randomised)
+LM_DEV float dr_attr(const lm_dr_channel& ch, uint32_t seed, uint32_t stream, int env, uint32_t dr_step, uint32_t reset_key, int idx, int comp, float base) {
+  if (!ch.enabled) return base;
+  uint32_t key = ch.interval > 0 ? dr_step / (uint32_t)ch.interval : reset_key;
+  if (ch.interval == 0 && key == 0) return base;
+  return dr_apply(ch.operation, base, dr_sample(seed, stream, (uint32_t)env, key, (uint32_t)idx, ch.distribution, ch.p0[comp], ch.p1[comp]));
+}
+struct DrPhys { float tmax[3], vmax[3]; V3 g, f; };      // this lane's three joints; gravity (world); base-link force (world)
 LM_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
   float sy, cy, sr, cr, sp, cp;
   sincosf(yaw * 0.5f, &sy, &cy); sincosf(roll * 0.5f, &sr, &cr); sincosf(pitch * 0.5f, &sp, &cp);
@@ -293,25 +313,28 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
 
 // One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
 // robot base is fixed at (Rb, pb).
-template <int MODE, int VAR>
+template <int MODE, int VAR, int DR>
 LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb, const Stash& St,
-                    FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3], float tau_acc[3]) {
-  const float dt = P->dt, kd = P->kd, tmax = P->tau_max, cj = VAR ? P->joint_damping : 0.f;
+                    FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3], float tau_acc[3], const DrPhys& X) {
+  const float dt = P->dt, kd = P->kd, cj = VAR ? P->joint_damping : 0.f;
+  const float tmax[3] = {DR ? X.tmax[0] : P->tau_max, DR ? X.tmax[1] : P->tau_max, DR ? X.tmax[2] : P->tau_max};
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
   float bn;
   {
     M3 Rb; V3 pb; SV v0;
     if (MODE == 0) { Rb = Rf; pb = F.p; v0 = F.u; } else { Rb = Rfix; pb = pfix; v0 = sv(v3(0, 0, 0), v3(0, 0, 0)); }
-    SV avp0 = sv(v3(0, 0, 0), P->gravity * row2(Rb));      // fictitious upward acceleration = gravity
+    SV avp0 = sv(v3(0, 0, 0), DR ? mulT(Rb, -X.g) : P->gravity * row2(Rb));      // fictitious acceleration = -gravity
     LimbKin K; limb_kinematics(tl, q, qd, K);
     LimbDyn D; limb_dynamics(tl, K, qd, v0, avp0, D);
     if (MODE == 0) {
       // the hub body itself rides on limb 0's contribution to the quad reductions
       const float m0 = (limb == 0) ? 1.f : 0.f;
       SI I0 = hub_inertia(th);
+      const V3 com0 = (1.0f / I0.m) * I0.h;
       I0.m *= m0; I0.h = m0 * I0.h; I0.xx *= m0; I0.yy *= m0; I0.zz *= m0; I0.xy *= m0; I0.xz *= m0; I0.yz *= m0;
       D.Isc = D.Isc + I0;
       D.fcs = D.fcs + I0 * avp0 + fcross(v0, I0 * v0);
+      if (DR) { V3 fh = m0 * mulT(Rb, X.f); D.fcs = D.fcs - sv(cross(com0, fh), fh); }      // randomised force on the base link, at its COM
     }
     // ---- contact geometry of this limb's tip
     V3 C0, C1, C2;        // contact axes (n, t1, t2) in hub coordinates
@@ -335,7 +358,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       // plate free motion
       SI Ip = load_si(P->plate_si);
       SV hp = fcross(F.u, Ip * F.u);
-      V3 fg = (-P->plate_mass * P->gravity) * row2(Rf);
+      V3 fg = DR ? P->plate_mass * mulT(Rf, X.g) : (-P->plate_mass * P->gravity) * row2(Rf);
       V3 c = v3(P->plate_com[0], P->plate_com[1], P->plate_com[2]);
       hp = hp - sv(cross(c, fg), fg);
       float Ph[6][6];
@@ -456,8 +479,8 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         float tau = kd * (tgt[a] - qdn[a]);
-        if (tau > tmax) { sat[a] = true; tsat[a] = tmax; any = 1; }
-        else if (tau < -tmax) { sat[a] = true; tsat[a] = -tmax; any = 1; }
+        if (tau > tmax[a]) { sat[a] = true; tsat[a] = tmax[a]; any = 1; }
+        else if (tau < -tmax[a]) { sat[a] = true; tsat[a] = -tmax[a]; any = 1; }
       }
       any = quad_sum_i(any);
       if (!__any(any)) break;                  // wave-uniform: nobody saturated
@@ -467,7 +490,8 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
 #pragma unroll
   for (int a = 0; a < 3; a++) {      // driven joints are speed-limited like PhysX's maxJointVelocity (config_module_joints.py:11,61-69)
     if (VAR) tau_acc[a] += sat[a] ? tsat[a] : kd * (tgt[a] - qdn[a]);      // drive torque applied over this sub-step
-    float v = fminf(fmaxf(qdn[a], -P->max_joint_vel), P->max_joint_vel);
+    const float vm = DR ? X.vmax[a] : P->max_joint_vel;
+    float v = fminf(fmaxf(qdn[a], -vm), vm);
     qd[a] = v; q[a] = fmaf(dt, v, q[a]);
   }
   F.u = un;
@@ -597,8 +621,24 @@ LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
 
 struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms, *partials; float *out_obs, *out_states, *out_rew; int64_t* out_resets; };
 
+struct DrOut { int64_t* drc; uint32_t seed, dr_step; int64_t rand_buf, reset_key; uint32_t* sKey; };      // sKey: LDS [16][2] {corr key, fire}
+
+template <int DR>
 LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int N, int env0, int lane, int limb, int env, bool active,
-                          const TaskState& S, const TaskOut& O, int64_t* cnt, int episode, float* sObs, float* sSt) {
+                          const TaskState& S, const TaskOut& O, int64_t* cnt, int episode, float* sObs, float* sSt, const DrOut& DO) {
+  if (DR) {
+    // observation-noise bookkeeping with the flags is_done has just written (vec_env_rlgames.py:70-72; randomize.py:213-216,228-230)
+    int64_t oc = S.reset ? 0 : DO.drc[0 * (size_t)N + env];
+    oc += 1;
+    const lm_dr_channel& ci = P->dr[LM_DR_OBS_INTERVAL];
+    const bool fire = ci.enabled && oc >= ci.interval;
+    if (fire) oc = 0;
+    if (limb == 0) { DO.sKey[2 * (lane >> 2)] = (uint32_t)episode + (S.reset ? 1u : 0u); DO.sKey[2 * (lane >> 2) + 1] = fire ? 1u : 0u; }
+    if (active && limb == 0) {
+      DO.drc[0 * (size_t)N + env] = oc; DO.drc[2 * (size_t)N + env] = (int64_t)DO.dr_step + 1;
+      DO.drc[3 * (size_t)N + env] = DO.rand_buf + 1; DO.drc[4 * (size_t)N + env] = DO.reset_key;
+    }
+  }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS staging writes landed (single wave per block)
   __builtin_amdgcn_wave_barrier();
   const float clip = P->clip_obs;
@@ -607,6 +647,18 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   // obs: nenv*NO floats contiguous (NO = 64 or 88, both multiples of 4)
   for (int i = lane; i < nenv * (NO / 4); i += 64) {
     float4 v = reinterpret_cast<const float4*>(sObs)[i];
+    if (DR) {      // noise in place on obs_buf, then the clipObservations clamp on the returned copy
+      const int el = (4 * i) / NO, col = (4 * i) - el * NO;
+      const uint32_t ckey = DO.sKey[2 * el], fire = DO.sKey[2 * el + 1], e = (uint32_t)(env0 + el);
+      const lm_dr_channel& cr = P->dr[LM_DR_OBS_RESET]; const lm_dr_channel& ci = P->dr[LM_DR_OBS_INTERVAL];
+      float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (cr.enabled) x[k] = dr_apply(cr.operation, x[k], dr_sample(DO.seed, LM_DR_OBS_RESET, e, ckey, (uint32_t)(col + k), cr.distribution, cr.p0[0], cr.p1[0]));
+        if (fire) x[k] = dr_apply(ci.operation, x[k], dr_sample(DO.seed, LM_DR_OBS_INTERVAL, e, DO.dr_step, (uint32_t)(col + k), ci.distribution, ci.p0[0], ci.p1[0]));
+      }
+      v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
+    }
     reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NO)[i] = v;
     if (W.out_obs) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
       reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NO)[i] = v; }
@@ -659,9 +711,11 @@ struct StepArgs {
   const float* actions; const float* goal_rand; OutPtrs W; int N, split; uint32_t seed;
   int skip_reset;   // 1: leave reset_buf untouched (staged API: resets were applied by lm_apply_resets)
   int nsub;         // < 0: params.substeps, otherwise that many sub-steps (0 = read-back + task layer only)
+  int64_t* drc;     // domain-randomisation counters [LM_DR_CNT_ROWS][N] (k_step_dr only)
+  float* dr_phys;   // [30][N] attributes sampled for this step (k_step_dr only)
 };
 
-template <int MODE, int VAR>
+template <int MODE, int VAR, int DR>
 LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const float* sTab, float* sObs, float* sSt, float4* sStash) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
   const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
@@ -681,8 +735,49 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     q[a] = st[(size_t)(R_Q + jj[a]) * N + env]; qd[a] = st[(size_t)(R_QD + jj[a]) * N + env];
-    act[a] = clampf(A.actions[(size_t)env * 12 + jj[a]], P->clip_actions);
+    act[a] = A.actions[(size_t)env * 12 + jj[a]];
   }
+  DrPhys X; uint32_t dr_step = 0; int64_t dr_rand_buf = 0, dr_reset_key = 0;
+  if (DR) {
+    // ---- action noise on the raw actions (vec_env_rlgames.py:56-58; randomize.py:237-259): correlated noise keyed by the episode this
+    // step belongs to (redrawn exactly when the reset flag is set), uncorrelated noise every frequency_interval calls
+    int64_t* dc = A.drc;
+    const uint32_t ep_now = (uint32_t)cnt[5 * (size_t)N + env] + (do_reset ? 1u : 0u);
+    dr_step = (uint32_t)dc[2 * (size_t)N + env]; dr_rand_buf = dc[3 * (size_t)N + env]; dr_reset_key = dc[4 * (size_t)N + env];
+    int64_t ac = do_reset ? 0 : dc[1 * (size_t)N + env];
+    ac += 1;
+    const lm_dr_channel& cr = P->dr[LM_DR_ACT_RESET]; const lm_dr_channel& ci = P->dr[LM_DR_ACT_INTERVAL];
+    const bool fire = ci.enabled && ac >= ci.interval;
+    if (fire) ac = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (cr.enabled) act[a] = dr_apply(cr.operation, act[a], dr_sample(A.seed, LM_DR_ACT_RESET, (uint32_t)env, ep_now, (uint32_t)jj[a], cr.distribution, cr.p0[0], cr.p1[0]));
+      if (fire) act[a] = dr_apply(ci.operation, act[a], dr_sample(A.seed, LM_DR_ACT_INTERVAL, (uint32_t)env, dr_step, (uint32_t)jj[a], ci.distribution, ci.p0[0], ci.p1[0]));
+    }
+    if (active && limb == 0) dc[1 * (size_t)N + env] = ac;
+    // ---- gated on_reset randomisation (quadruped_pose_control.py:224-228), then this control step's physics attributes
+    if (do_reset && dr_rand_buf >= P->dr_min_frequency) { dr_reset_key = ep_now; dr_rand_buf = 0; }
+    const float g0[3] = {0.f, 0.f, -P->gravity}; float gv[3], fv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      gv[c] = dr_attr(P->dr[LM_DR_GRAVITY], A.seed, LM_DR_GRAVITY, env, dr_step, (uint32_t)dr_reset_key, c, c, g0[c]);
+      fv[c] = dr_attr(P->dr[LM_DR_BASE_FORCE], A.seed, LM_DR_BASE_FORCE, env, dr_step, (uint32_t)dr_reset_key, c, c, 0.f);
+      X.tmax[c] = dr_attr(P->dr[LM_DR_MAX_EFFORT], A.seed, LM_DR_MAX_EFFORT, env, dr_step, (uint32_t)dr_reset_key, jj[c], 0, P->tau_max);
+      X.vmax[c] = dr_attr(P->dr[LM_DR_MAX_VELOCITY], A.seed, LM_DR_MAX_VELOCITY, env, dr_step, (uint32_t)dr_reset_key, jj[c], 0, P->max_joint_vel);
+    }
+    X.g = v3(gv[0], gv[1], gv[2]); X.f = v3(fv[0], fv[1], fv[2]);
+    if (active) {
+      float* ph = A.dr_phys;
+#pragma unroll
+      for (int c = 0; c < 3; c++) { ph[(size_t)jj[c] * N + env] = X.tmax[c]; ph[(size_t)(12 + jj[c]) * N + env] = X.vmax[c]; }
+      if (limb == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { ph[(size_t)(24 + c) * N + env] = gv[c]; ph[(size_t)(27 + c) * N + env] = fv[c]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) act[a] = clampf(act[a], P->clip_actions);
   // ---- reset_idx (quadruped_pose_control.py:230-299), physical part
   if (do_reset) {
 #pragma unroll
@@ -704,7 +799,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   if (!pd) {
     // ---- take_action (robot.py:452-454): velocity targets
     float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
-    for (int s = 0; s < nsub; s++) substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+    for (int s = 0; s < nsub; s++) substep<MODE, VAR, DR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc, X);
   } else {
     // ---- custom-controller tasks (quadruped_pose_control_custom_controller.py:255-307): the action integrates the swing / extension
     // position targets; the actuator torque  clamp(kp (q* - q) - kd qd, +-tau_max)  is re-evaluated every sub-step.  It is the same drive
@@ -724,7 +819,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
       // trailing acc_substeps (= controlFrequencyInv) sub-steps (robot.py:289-291)
       if (s == nsub - P->acc_substeps) { qda[0] = qd[0]; qda[1] = qd[1]; qda[2] = qd[2]; qda_set = true; }
       float tgt[3] = {g * (tgtq[0] - q[0]), g * (tgtq[1] - q[1]), g * (tgtq[2] - q[2])};
-      substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+      substep<MODE, VAR, DR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc, X);
     }
   }
   // ---- task-layer state
@@ -814,7 +909,9 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
       st[(size_t)(R_GOAL + 0) * N + env] = S.goal.w; st[(size_t)(R_GOAL + 1) * N + env] = S.goal.x; st[(size_t)(R_GOAL + 2) * N + env] = S.goal.y; st[(size_t)(R_GOAL + 3) * N + env] = S.goal.z;
     }
   }
-  write_outputs(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt);
+  DrOut DO; DO.drc = A.drc; DO.seed = A.seed; DO.dr_step = dr_step; DO.rand_buf = dr_rand_buf; DO.reset_key = dr_reset_key;
+  DO.sKey = reinterpret_cast<uint32_t*>(sStash);      // the stash is dead after the last sub-step
+  write_outputs<DR>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
 }
 
 __global__ void __launch_bounds__(64) k_step(StepArgs A) {
@@ -825,9 +922,23 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   load_table(A.table, sTab, threadIdx.x);
   const int env0 = blockIdx.x * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
-  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0>(A, P, sTab, sObs, sSt, sStash); }
-  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1>(A, P, sTab, sObs, sSt, sStash); }
-  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2>(A, P, sTab, sObs, sSt, sStash); }
+  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash); }
+  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(A, P, sTab, sObs, sSt, sStash); }
+}
+
+// the same step with domain randomisation (a separate kernel so that the un-randomised k_step above is untouched)
+__global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
+  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
+  __shared__ float4 sStash[STASH_SLOTS * 64];
+  load_table(A.table, sTab, threadIdx.x);
+  const int env0 = blockIdx.x * ENVS_PER_WAVE;
+  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash); }
+  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 1>(A, P, sTab, sObs, sSt, sStash); }
 }
 
 // means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps
@@ -964,7 +1075,8 @@ LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sT
   M3 Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   float tau_acc[3] = {0.f, 0.f, 0.f};
-  for (int s = 0; s < n; s++) substep<MODE, VAR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc);
+  DrPhys X;
+  for (int s = 0; s < n; s++) substep<MODE, VAR, 0>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc, X);
   if (active) store_phys<MODE>(A.state, N, env, limb, F, q, qd);
 }
 __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* targets, int n) {
@@ -1061,7 +1173,8 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
     if (limb == 0) st[(size_t)R_LRD * N + env] = S.lrd;
     st[(size_t)(R_LTIP + 3 * limb) * N + env] = S.ltip.x; st[(size_t)(R_LTIP + 3 * limb + 1) * N + env] = S.ltip.y; st[(size_t)(R_LTIP + 3 * limb + 2) * N + env] = S.ltip.z;
   }
-  write_outputs(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt);
+  DrOut DO{};
+  write_outputs<0>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
 }
 __global__ void __launch_bounds__(64) k_task_eval(StepArgs A, const float* readback) {
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
@@ -1117,13 +1230,23 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || p.variant < 0 || p.variant > 2 ||
         (p.variant == 1) != (p.num_obs == LM_MAX_OBS) || (p.variant >= 1 && !(p.kd > 0 && p.torque_div > 0 && p.acc_substeps >= 1 && p.acc_substeps <= p.substeps)))
       return fail(LM_EINVAL, "lm_create: invalid variant / num_obs (64 for velocity-drive and position-control tasks, 88 for custom-controller tasks, equal across tasks) or acc_substeps");
+    if ((p.dr_enabled != 0) != (params[0].dr_enabled != 0)) return fail(LM_EINVAL, "lm_create: dr_enabled must be equal across tasks");
+    if (p.dr_enabled) for (int c = 0; c < LM_DR_CHANNELS; c++) {
+      const lm_dr_channel& ch = p.dr[c];
+      if (!ch.enabled) continue;
+      const bool noise_reset = (c == LM_DR_OBS_RESET || c == LM_DR_ACT_RESET), noise_interval = (c == LM_DR_OBS_INTERVAL || c == LM_DR_ACT_INTERVAL);
+      if (ch.operation < 0 || ch.operation > 2 || ch.distribution < 0 || ch.distribution > 2 || ch.interval < 0 ||
+          (noise_reset && ch.interval != 0) || (noise_interval && ch.interval < 1) || ((noise_reset || noise_interval) && ch.operation == LM_DR_DIRECT) ||
+          (ch.distribution == LM_DR_LOGUNIFORM && !(ch.p0[0] > 0 && ch.p1[0] > 0)) || p.dr_min_frequency < 0)
+        return fail(LM_EINVAL, "lm_create: invalid domain-randomisation channel (operation / distribution / interval / parameters)");
+    }
   }
   lm_engine* h = new (std::nothrow) lm_engine();
   if (!h) return fail(LM_ENOMEM, "lm_create: host allocation failed");
   memset(h, 0, sizeof(*h));
   h->N = n_envs; h->n_tasks = n_tasks; h->split = (n_tasks == 2) ? split_env : n_envs; h->seed = seed;
   h->nblocks = (n_envs + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE;
-  h->num_obs = params[0].num_obs;
+  h->num_obs = params[0].num_obs; h->dr_enabled = params[0].dr_enabled != 0;
   h->h_params[0] = params[0]; h->h_params[1] = params[n_tasks - 1];
   derive_params(&h->h_params[0]); derive_params(&h->h_params[1]);
   size_t N = (size_t)n_envs;
@@ -1133,6 +1256,8 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_table, LM_TABLE_FLOATS * sizeof(float));
   ALLOC(h->d_state, LM_STATE_ROWS * N * sizeof(float));
   ALLOC(h->d_cnt, LM_CNT_ROWS * N * sizeof(int64_t));
+  ALLOC(h->d_drc, LM_DR_CNT_ROWS * N * sizeof(int64_t));
+  ALLOC(h->d_dr_phys, 30 * N * sizeof(float));
   ALLOC(h->d_obs, N * (size_t)h->num_obs * sizeof(float));
   ALLOC(h->d_states, N * 93 * sizeof(float));
   ALLOC(h->d_rew, N * sizeof(float));
@@ -1158,7 +1283,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
 
 int lm_destroy(lm_engine* h) {
   if (!h) return LM_OK;
-  void* ptrs[] = {h->d_params, h->d_table, h->d_state, h->d_cnt, h->d_obs, h->d_states, h->d_rew, h->d_extras, h->d_terms, h->d_partials, h->d_stats};
+  void* ptrs[] = {h->d_params, h->d_table, h->d_state, h->d_cnt, h->d_drc, h->d_dr_phys, h->d_obs, h->d_states, h->d_rew, h->d_extras, h->d_terms, h->d_partials, h->d_stats};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return LM_OK;
@@ -1169,7 +1294,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
   A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.partials = h->d_partials;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
-  A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1;
+  A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
   return A;
 }
 
@@ -1178,7 +1303,8 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
   if (!h || !actions) return fail(LM_EINVAL, "lm_step: null handle or actions");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets);
-  hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
+  if (h->dr_enabled) hipLaunchKernelGGL(k_step_dr, dim3(h->nblocks), dim3(64), 0, s, A);
+  else hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
@@ -1187,6 +1313,7 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
 int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* out_states, float* out_rew,
                     int64_t* out_resets, float* out_extras, void* stream) {
   if (!h || !actions) return fail(LM_EINVAL, "lm_post_physics: null handle or actions");
+  if (h->dr_enabled) return fail(LM_EINVAL, "lm_post_physics: a randomised engine runs through lm_step only");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
   A.skip_reset = 1; A.nsub = 0;
@@ -1254,6 +1381,8 @@ void* lm_ptr(lm_engine* h, int kind) {
   switch (kind) {
     case LM_PTR_STATE: return h->d_state;
     case LM_PTR_CNT: return h->d_cnt;
+    case LM_PTR_DR_CNT: return h->d_drc;
+    case LM_PTR_DR_PHYS: return h->d_dr_phys;
     case LM_PTR_OBS_BUF: return h->d_obs;
     case LM_PTR_STATES_BUF: return h->d_states;
     case LM_PTR_REW_BUF: return h->d_rew;

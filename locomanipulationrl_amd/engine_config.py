@@ -30,6 +30,29 @@ def _f(x):
     return field(default_factory=lambda: list(x))
 
 
+# ---- domain randomisation (YAML schema of cfg/task/QuadrupedPoseControl.yaml:102-173)
+DR_OBS_RESET, DR_OBS_INTERVAL, DR_ACT_RESET, DR_ACT_INTERVAL, DR_GRAVITY, DR_BASE_FORCE, DR_MAX_EFFORT, DR_MAX_VELOCITY = range(8)
+DR_CHANNELS = 8
+DR_OPERATIONS = {"additive": 0, "scaling": 1, "direct": 2}
+DR_DISTRIBUTIONS = {"gaussian": 0, "normal": 0, "uniform": 1, "loguniform": 2, "log_uniform": 2}
+
+
+@dataclass
+class DRChannel:
+    """One randomised quantity: operation / distribution / distribution_parameters of the YAML; `interval` = frequency_interval
+    for on_interval entries, 0 for on_reset entries.  p0 / p1 = gaussian mean / std or uniform low / high (3 components for vectors)."""
+    enabled: int = 0
+    operation: int = 0
+    distribution: int = 0
+    interval: int = 0
+    p0: List[float] = _f([0.0, 0.0, 0.0])
+    p1: List[float] = _f([0.0, 0.0, 0.0])
+
+
+def _no_dr():
+    return [DRChannel() for _ in range(DR_CHANNELS)]
+
+
 @dataclass
 class EngineParams:
     # ---- physics
@@ -108,6 +131,10 @@ class EngineParams:
     rot_dec_thresh: float = 0.3
     acc_substeps: int = 1               # variants 1/2: the joint acceleration spans the trailing controlFrequencyInv sub-steps (robot.py:289-291)
     cc_update_last_tgt: int = 1         # loco: last targets follow the targets (:723-725); the mani variant never updates them after reset
+    # ---- domain randomisation (off in every YAML of the measured path)
+    dr_enabled: int = 0
+    dr_min_frequency: int = 1
+    dr: List[DRChannel] = field(default_factory=_no_dr)
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 

@@ -17,7 +17,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.environ.get("LM_ENGINE_SO", os.path.join(_CSRC, "liblm_engine.so"))     # override: kernel experiments only
 
 STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS, TERM_ROWS, READBACK = 115, 6, 64, 93, 12, 13, 486, 11, 99
-PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS = range(8)
+PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS, PTR_DR_CNT, PTR_DR_PHYS = range(10)
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
@@ -28,6 +28,11 @@ EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_al
 ROW = dict(base_pos=0, base_quat=3, base_lin=7, base_ang=10, q=13, qd=25, plate_pos=37, plate_quat=40, plate_lin=44,
            plate_ang=47, last_actions=50, last_qd=62, last_tip=74, goal=86)
 CNT = dict(successes=0, consecutive_successes=1, goal_reset_buf=2, reset_buf=3, progress_buf=4, episode_count=5)
+
+
+class LmDrChannel(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("operation", C.c_int32), ("distribution", C.c_int32), ("interval", C.c_int32),
+                ("p0", C.c_float * 3), ("p1", C.c_float * 3)]
 
 
 class LmParams(C.Structure):
@@ -54,6 +59,7 @@ class LmParams(C.Structure):
         ("se_lo", C.c_float * 12), ("se_hi", C.c_float * 12), ("init_se", C.c_float * 12),
         ("torque_div", C.c_float), ("power_scale", C.c_float), ("target_err_scale", C.c_float), ("rot_dec_scale", C.c_float),
         ("rot_dec_thresh", C.c_float), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
+        ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmDrChannel * 8),
         ("plate_si", C.c_float * 10), ("plate_phi", C.c_float * 36), ("ctrl_dt_inv", C.c_float), ("acc_dt_inv", C.c_float),
     ]
 
@@ -71,6 +77,12 @@ def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParam
             p.clip_obs = float(clip_obs); continue
         if name == "clip_actions":
             p.clip_actions = float(clip_actions); continue
+        if name == "dr":
+            for i, ch in enumerate(ep.dr):
+                p.dr[i].enabled, p.dr[i].operation, p.dr[i].distribution, p.dr[i].interval = int(ch.enabled), int(ch.operation), int(ch.distribution), int(ch.interval)
+                for c in range(3):
+                    p.dr[i].p0[c] = float(ch.p0[c]); p.dr[i].p1[c] = float(ch.p1[c])
+            continue
         val = getattr(ep, name)
         if isinstance(val, (list, tuple, np.ndarray)):
             arr = np.asarray(val, dtype=np.float64)
@@ -182,6 +194,8 @@ class Engine:
         self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
         self.terms = self._wrap(PTR_TERMS, (TERM_ROWS, N), "<f4")
         self.stats_i64 = self._wrap(PTR_STATS, (6,), "<i8")
+        self.dr_cnt = self._wrap(PTR_DR_CNT, (5, N), "<i8")          # domain-randomisation counters
+        self.dr_phys = self._wrap(PTR_DR_PHYS, (30, N), "<f4")       # attributes sampled for the last step
 
     # ------------------------------------------------------------------
     def _check(self, rc: int):

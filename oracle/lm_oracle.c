@@ -77,6 +77,42 @@ void lmo_hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, real* u3) 
 }
 int lmo_sizeof_real(void) { return (int)sizeof(real); }
 
+/* ------------------------------------------------------------------ domain randomisation: counter-based samples */
+real lmo_dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, uint32_t idx, int distribution, real p0, real p1) {
+  uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ mix32(stream * 0x27D4EB2FU + 0x632BE5ABU));
+  uint32_t r1 = mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  real u1 = ((real)(r1 >> 8) + (real)1) * (real)(1.0 / 16777216.0);     /* (0, 1] */
+  real u2 = (real)(r2 >> 8) * (real)(1.0 / 16777216.0);                 /* [0, 1) */
+  if (distribution == 0) return p0 + p1 * (real)(sqrt(-2 * log(u1)) * cos((real)6.283185307179586 * u2));     /* torch.normal(mean, std) */
+  if (distribution == 1) return p0 + (p1 - p0) * u2;                                                       /* (hi-lo)*rand + lo */
+  return (real)exp(log(p0) + (log(p1) - log(p0)) * u2);                                                      /* loguniform */
+}
+
+static real dr_apply(int operation, real x, real n) { return operation == 0 ? x + n : (operation == 1 ? x * n : n); }
+
+void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_interval, uint32_t seed, uint32_t stream, int N, int D,
+                  real* buf, const int64_t* reset_flags, int64_t* counter, const int64_t* corr_key, const int64_t* step_key) {
+  for (int e = 0; e < N; e++) {
+    real* b = buf + (size_t)e * D;
+    /* randomize.py:213-216 / 237-240: counter[reset ids] = 0; counter += 1 */
+    if (reset_flags[e]) counter[e] = 0;
+    counter[e] += 1;
+    /* :218-226: correlated noise, redrawn for the envs whose reset flag is set, applied to every env on every call */
+    if (on_reset && on_reset->enabled)
+      for (int j = 0; j < D; j++)
+        b[j] = dr_apply(on_reset->operation, b[j], lmo_dr_sample(seed, stream, (uint32_t)e, (uint32_t)corr_key[e], (uint32_t)j, on_reset->distribution, (real)on_reset->p0[0], (real)on_reset->p1[0]));
+    /* :228-236: uncorrelated noise for the envs whose counter reached frequency_interval */
+    if (on_interval && on_interval->enabled && counter[e] >= on_interval->interval) {
+      counter[e] = 0;
+      for (int j = 0; j < D; j++)
+        b[j] = dr_apply(on_interval->operation, b[j], lmo_dr_sample(seed, stream + 1U, (uint32_t)e, (uint32_t)step_key[e], (uint32_t)j, on_interval->distribution, (real)on_interval->p0[0], (real)on_interval->p1[0]));
+    }
+  }
+}
+
+typedef struct { real tmax[12], vmax[12], g[3], f[3]; } env_dr_t;
+static __thread const env_dr_t* g_dr = 0;      /* per-env physics overrides while lmo_step_dr runs a sub-step */
+
 /* ------------------------------------------------------------------ kinematics */
 typedef struct {
   real Rw[LMO_MAXB][9], ow[LMO_MAXB][3], zw[LMO_MAXB][3], cw[LMO_MAXB][3], Iw[LMO_MAXB][9];
@@ -195,7 +231,10 @@ static void dyn_compute(const lmo_model* m, const lmo_params* p, const real* phy
     cross(al[k], rc, t); cross(w[k], rc, t2); cross(w[k], t2, t2);
     for (int i=0;i<3;i++) ac[i]=ao[k][i]+t[i]+t2[i];
     m3v(K.Iw[k], w[k], Iw_); cross(w[k], Iw_, t); m3v(K.Iw[k], al[k], nA);
-    for (int i=0;i<3;i++) { nA[i]+=t[i]; fL[i]=mass*ac[i]; } fL[2]+=mass*(real)p->gravity;
+    for (int i=0;i<3;i++) { nA[i]+=t[i]; fL[i]=mass*ac[i]; }
+    if (!g_dr) fL[2]+=mass*(real)p->gravity;
+    else { for (int i=0;i<3;i++) fL[i]-=mass*g_dr->g[i];                 /* randomised gravity vector */
+           if (m->parent[k]<0) for (int i=0;i<3;i++) fL[i]-=g_dr->f[i]; }   /* external force on the base link, at its COM, world axes */
     for (int a=0;a<NU;a++) {
       real IJ[3]; real ja[3]={JA[0][a],JA[1][a],JA[2][a]}; m3v(K.Iw[k], ja, IJ);
       for (int b=a;b<NU;b++) { real s=0; for (int i=0;i<3;i++) s += IJ[i]*JA[i][b] + mass*JL[i][a]*JL[i][b]; D->M[a][b]+=s; }
@@ -232,7 +271,7 @@ static void dyn_compute(const lmo_model* m, const lmo_params* p, const real* phy
     cross(wpl, n, t); cross(vpl, f, t2); for (int i=0;i<3;i++) D->h[i]=t[i]+t2[i];
     cross(wpl, f, t); for (int i=0;i<3;i++) D->h[3+i]=t[i];
     /* gravity force in plate coords at COM */
-    real gw[3]={0,0,-(real)p->gravity}, gb[3]; m3Tv(D->Rf, gw, gb);
+    real gw[3]={0,0,-(real)p->gravity}, gb[3]; if (g_dr) for (int i=0;i<3;i++) gw[i]=g_dr->g[i]; m3Tv(D->Rf, gw, gb);
     real fg[3]={mp*gb[0],mp*gb[1],mp*gb[2]}, ng[3]; cross(c, fg, ng);
     for (int i=0;i<3;i++) { D->h[i]-=ng[i]; D->h[3+i]-=fg[i]; }
   }
@@ -310,12 +349,12 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
     if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];
-    if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); if (tau>tmax){sat[j]=1;tsat[j]=tmax;any=1;} else if (tau<-tmax){sat[j]=1;tsat[j]=-tmax;any=1;} }
+    if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
       if (!any) break; }
   }
   if (tau_out) for (int j=0;j<12;j++) tau_out[j] = sat[j] ? tsat[j] : kd*(target[j]-un[6+j]);   /* drive torque applied over this sub-step */
   /* integrate; driven joints are speed-limited like PhysX's maxJointVelocity (Design/Scripts/config_module_joints.py:11,61-69) */
-  for (int j=0;j<12;j++) { real v=un[6+j]; real vm=(real)p->max_joint_vel; if (v>vm) v=vm; if (v<-vm) v=-vm; phys[25+j]=v; phys[13+j]+=dt*v; }
+  for (int j=0;j<12;j++) { real v=un[6+j]; real vm=g_dr?g_dr->vmax[j]:(real)p->max_joint_vel; if (v>vm) v=vm; if (v<-vm) v=-vm; phys[25+j]=v; phys[13+j]+=dt*v; }
   {
     real* pos  = (p->mode==0)? phys   : phys+37;
     real* quat = (p->mode==0)? phys+3 : phys+40;
@@ -503,9 +542,14 @@ void lmo_reset(const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
   }
 }
 
-void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
-              const real* actions, const real* goal_rand, uint32_t seed,
-              real* obs, real* states, real* rew, real* terms) {
+static void substeps_all(const lmo_model* m, const lmo_params* p, int N, real* phys, const real* targets, real* tau, const env_dr_t* drs) {
+  #pragma omp parallel for schedule(static)
+  for (int e=0;e<N;e++) { g_dr = drs ? drs+e : 0; substep_one(m, p, phys+(size_t)e*LMO_PHYS, targets+(size_t)e*12, tau?tau+(size_t)e*12:NULL); g_dr = 0; }
+}
+
+static void step_core(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
+                      const real* actions, const real* goal_rand, uint32_t seed,
+                      real* obs, real* states, real* rew, real* terms, const env_dr_t* drs) {
   lmo_reset(p, N, phys, task, cnt, goal_rand, seed);
   real* targets=(real*)malloc(sizeof(real)*12*(size_t)N);
   real* rb=(real*)malloc(sizeof(real)*LMO_READBACK*(size_t)N);
@@ -513,7 +557,7 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
   if (p->variant==0) {
     /* robot.py:452-454: velocity mode, unscale_transform(a, -lim, +lim) = a*lim */
     for (size_t i=0;i<(size_t)N*12;i++) targets[i]=actions[i]*(real)p->act_scale;
-    for (int s=0;s<p->substeps;s++) lmo_substep(m, p, N, phys, targets);
+    for (int s=0;s<p->substeps;s++) substeps_all(m, p, N, phys, targets, NULL, drs);
   } else {
     /* quadruped_pose_control_custom_controller.py:255-307: integrate swing/extension targets, PD torque every sub-step */
     real* tau=(real*)malloc(sizeof(real)*12*(size_t)N);
@@ -527,7 +571,7 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
         for (int l=0;l<4;l++) { qs[l]=se[l]; qs[4+2*l]=se[4+2*l]+se[5+2*l]/2; qs[5+2*l]=se[4+2*l]-se[5+2*l]/2; }
         /* tau = kp (q* - q) - kd qd  ==  kd (v* - qd)  with  v* = kp/kd (q* - q): the velocity-drive solver with a position-derived target */
         for (int i=0;i<12;i++) tg[i]=(real)p->pd_kp/(real)p->kd*(qs[i]-q[i]); }
-      lmo_substep_tau(m, p, N, phys, targets, tau);
+      substeps_all(m, p, N, phys, targets, tau, drs);
       for (size_t i=0;i<(size_t)N*12;i++) tausum[i]+=tau[i];
     }
     free(tau);
@@ -545,4 +589,53 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
   }
   lmo_task_eval(p, N, rb, actions, task, cnt, obs, states, rew, terms);
   free(targets); free(rb); free(tausum);
+}
+
+void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt,
+              const real* actions, const real* goal_rand, uint32_t seed,
+              real* obs, real* states, real* rew, real* terms) {
+  step_core(m, p, N, phys, task, cnt, actions, goal_rand, seed, obs, states, rew, terms, NULL);
+}
+
+/* one randomised physics attribute of one env: on_interval entries are redrawn every `interval` control steps
+ * (key = dr_step / interval), on_reset entries at the env's last gated reset (key = dr_reset_key; 0 = never randomised) */
+static real dr_attr(const lmo_dr_channel* ch, uint32_t seed, uint32_t stream, int e, const int64_t* d, int idx, int comp, real base) {
+  if (!ch->enabled) return base;
+  int64_t key = ch->interval > 0 ? d[2] / ch->interval : d[4];
+  if (ch->interval == 0 && key == 0) return base;
+  real n = lmo_dr_sample(seed, stream, (uint32_t)e, (uint32_t)key, (uint32_t)idx, ch->distribution, (real)ch->p0[comp], (real)ch->p1[comp]);
+  return dr_apply(ch->operation, base, n);
+}
+
+void lmo_step_dr(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt, int64_t* drc,
+                 const real* actions_raw, real clip_actions, const real* goal_rand, uint32_t seed,
+                 real* obs, real* states, real* rew, real* terms, real* actions_used, real* physdr) {
+  int64_t* flags=(int64_t*)calloc((size_t)N*4, sizeof(int64_t)); int64_t *rf=flags, *key=flags+N, *stepk=flags+2*(size_t)N, *cntr=flags+3*(size_t)N;
+  real* act=(real*)malloc(sizeof(real)*12*(size_t)N); memcpy(act, actions_raw, sizeof(real)*12*(size_t)N);
+  env_dr_t* drs=(env_dr_t*)malloc(sizeof(env_dr_t)*(size_t)N);
+  /* 1. action noise on the raw actions, then the clipActions clamp (vec_env_rlgames.py:56-60) */
+  for (int e=0;e<N;e++) { rf[e]=cnt[(size_t)e*LMO_CNT+3]!=0; key[e]=cnt[(size_t)e*LMO_CNT+5]+rf[e]; stepk[e]=drc[(size_t)e*LMO_DR_CNT+2]; cntr[e]=drc[(size_t)e*LMO_DR_CNT+1]; }
+  lmo_dr_noise(&p->dr[LMO_DR_ACT_RESET], &p->dr[LMO_DR_ACT_INTERVAL], seed, LMO_DR_ACT_RESET, N, 12, act, rf, cntr, key, stepk);
+  for (int e=0;e<N;e++) drc[(size_t)e*LMO_DR_CNT+1]=cntr[e];
+  for (size_t i=0;i<(size_t)N*12;i++) { if (act[i]>clip_actions) act[i]=clip_actions; if (act[i]<-clip_actions) act[i]=-clip_actions; }
+  if (actions_used) memcpy(actions_used, act, sizeof(real)*12*(size_t)N);
+  /* 2. gated on_reset randomisation (quadruped_pose_control.py:224-228) and 3. this control step's physics attributes */
+  for (int e=0;e<N;e++) {
+    int64_t* d=drc+(size_t)e*LMO_DR_CNT;
+    if (rf[e] && d[3]>=p->dr_min_frequency) { d[4]=key[e]; d[3]=0; }
+    env_dr_t* x=drs+e;
+    const real g0[3]={0,0,-(real)p->gravity};
+    for (int c=0;c<3;c++) { x->g[c]=dr_attr(&p->dr[LMO_DR_GRAVITY], seed, LMO_DR_GRAVITY, e, d, c, c, g0[c]);
+                            x->f[c]=dr_attr(&p->dr[LMO_DR_BASE_FORCE], seed, LMO_DR_BASE_FORCE, e, d, c, c, 0); }
+    for (int j=0;j<12;j++) { x->tmax[j]=dr_attr(&p->dr[LMO_DR_MAX_EFFORT], seed, LMO_DR_MAX_EFFORT, e, d, j, 0, (real)p->tau_max);
+                             x->vmax[j]=dr_attr(&p->dr[LMO_DR_MAX_VELOCITY], seed, LMO_DR_MAX_VELOCITY, e, d, j, 0, (real)p->max_joint_vel); }
+    if (physdr) { real* o=physdr+(size_t)e*30; for (int j=0;j<12;j++){o[j]=x->tmax[j];o[12+j]=x->vmax[j];} for (int c=0;c<3;c++){o[24+c]=x->g[c];o[27+c]=x->f[c];} }
+  }
+  /* 4./5. the step itself */
+  step_core(m, p, N, phys, task, cnt, act, goal_rand, seed, obs, states, rew, terms, drs);
+  /* 6. observation noise in place on obs_buf, keyed by the flags is_done has just written (vec_env_rlgames.py:70-72) */
+  for (int e=0;e<N;e++) { rf[e]=cnt[(size_t)e*LMO_CNT+3]!=0; key[e]=cnt[(size_t)e*LMO_CNT+5]+rf[e]; cntr[e]=drc[(size_t)e*LMO_DR_CNT+0]; }
+  lmo_dr_noise(&p->dr[LMO_DR_OBS_RESET], &p->dr[LMO_DR_OBS_INTERVAL], seed, LMO_DR_OBS_RESET, N, p->num_obs, obs, rf, cntr, key, stepk);
+  for (int e=0;e<N;e++) { int64_t* d=drc+(size_t)e*LMO_DR_CNT; d[0]=cntr[e]; d[2]+=1; d[3]+=1; }
+  free(flags); free(act); free(drs);
 }

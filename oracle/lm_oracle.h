@@ -56,6 +56,17 @@ typedef struct {
   int32_t knee_body[8];
 } lmo_model;
 
+#define LMO_DR_CHANNELS 8
+enum { LMO_DR_OBS_RESET = 0, LMO_DR_OBS_INTERVAL, LMO_DR_ACT_RESET, LMO_DR_ACT_INTERVAL, LMO_DR_GRAVITY, LMO_DR_BASE_FORCE, LMO_DR_MAX_EFFORT,
+       LMO_DR_MAX_VELOCITY };
+typedef struct {
+  int32_t enabled;
+  int32_t operation;       /* 0 additive, 1 scaling, 2 direct */
+  int32_t distribution;    /* 0 gaussian, 1 uniform, 2 loguniform */
+  int32_t interval;        /* frequency_interval of an on_interval entry; 0 = on_reset entry */
+  double p0[3], p1[3];     /* distribution_parameters: mean/std or low/high (per component for vector attributes) */
+} lmo_dr_channel;
+
 typedef struct {
   /* physics */
   double dt;                 /* 0.0083 */
@@ -114,6 +125,11 @@ typedef struct {
   int32_t cc_update_last_tgt;  /* 1: last_joint_position_targets follows the targets (loco, :723-725); 0: stays at its reset value
                                   (quadruped_manipulate_plate_custom_controller.py never updates it after :378) */
   int32_t acc_substeps;      /* variants 1/2: trailing sub-steps spanned by the joint acceleration (controlFrequencyInv; robot.py:289-291) */
+  /* ---- domain randomisation: utils/domain_randomization/randomize.py:212-306 (observation / action noise, pinned by
+   * tests/golden/dr_noise.npz) and the physics attributes of cfg/task/QuadrupedPoseControl.yaml:136-173 (gravity, base-link force,
+   * max efforts, max joint velocities; their sampling lives in omni.replicator.isaac, absent: this repo's specification) */
+  int32_t dr_enabled, dr_min_frequency;
+  lmo_dr_channel dr[LMO_DR_CHANNELS];
 } lmo_params;
 
 /* per-env physical state, env-major */
@@ -133,6 +149,11 @@ typedef struct {
 /*  rot_rew, translation_penalty, joint_acc_penalty, action_rate_penalty,
  *  consecutive_successes_rew, joint_limit_penalty, fall_penalty, goal_reset (as real),
  *  mechanical_power_penalty, position_target_error_penalty, rot_dist_decreasing_reward */
+
+#define LMO_DR_CNT 5
+/*  per-env randomisation counters (int64): observation noise counter, action noise counter (randomize.py:214-216,238-240),
+ *  dr_step (control steps since creation), randomization_buf (steps since the last gated on_reset randomisation,
+ *  quadruped_pose_control.py:224-228), dr_reset_key (episode index at that randomisation) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -167,6 +188,18 @@ void lmo_step(const lmo_model* m, const lmo_params* p, int N, real* phys, real* 
               real* obs, real* states, real* rew, real* terms);
 
 /* goal sampling helpers exposed for tests */
+/* counter-based sample of one randomised scalar: stream = quantity, key = episode / step / interval index, idx = component */
+real lmo_dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, uint32_t idx, int distribution, real p0, real p1);
+/* randomize.py:212-306 restated on an (N x D) buffer: correlated noise drawn when an env's reset flag is set (keyed by corr_key) and
+ * applied every call, plus uncorrelated noise (keyed by step_key) every `interval` calls; counter is the reference's per-env counter */
+void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_interval, uint32_t seed, uint32_t stream, int N, int D,
+                  real* buf, const int64_t* reset_flags, int64_t* counter, const int64_t* corr_key, const int64_t* step_key);
+/* lmo_step with domain randomisation: raw (unclamped) actions in; obs_noisy = what VecEnvRLGames.step hands to the policy before
+ * clamping (vec_env_rlgames.py:56-72).  drc = (N x LMO_DR_CNT) counters.  physdr (N x 30, may be NULL) receives the sampled
+ * max efforts (12), max velocities (12), gravity (3), base force (3) */
+void lmo_step_dr(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt, int64_t* drc,
+                 const real* actions_raw, real clip_actions, const real* goal_rand, uint32_t seed,
+                 real* obs, real* states, real* rew, real* terms, real* actions_used, real* physdr);
 void lmo_hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, real* u3);
 void lmo_quat_from_euler(real roll, real pitch, real yaw, real* q);
 int lmo_sizeof_real(void);

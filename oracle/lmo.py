@@ -27,6 +27,14 @@ class LmoModel(C.Structure):
     ]
 
 
+DR_CNT = 5
+
+
+class LmoDrChannel(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("operation", C.c_int32), ("distribution", C.c_int32), ("interval", C.c_int32),
+                ("p0", C.c_double * 3), ("p1", C.c_double * 3)]
+
+
 class LmoParams(C.Structure):
     _fields_ = [
         ("dt", C.c_double), ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("gravity", C.c_double),
@@ -50,6 +58,7 @@ class LmoParams(C.Structure):
         ("variant", C.c_int32), ("num_obs", C.c_int32), ("pd_kp", C.c_double), ("joint_damping", C.c_double), ("act_scale_se", C.c_double),
         ("se_lo", C.c_double * 12), ("se_hi", C.c_double * 12), ("init_se", C.c_double * 12), ("torque_div", C.c_double),
         ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
+        ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmoDrChannel * 8),
     ]
 
 
@@ -93,6 +102,12 @@ def make_params(ep) -> LmoParams:
     p = LmoParams()
     for name, ctype in LmoParams._fields_:
         if name in ("pad0",):
+            continue
+        if name == "dr":
+            for i, ch in enumerate(ep.dr):
+                p.dr[i].enabled, p.dr[i].operation, p.dr[i].distribution, p.dr[i].interval = int(ch.enabled), int(ch.operation), int(ch.distribution), int(ch.interval)
+                for c in range(3):
+                    p.dr[i].p0[c] = float(ch.p0[c]); p.dr[i].p1[c] = float(ch.p1[c])
             continue
         val = getattr(ep, name)
         if isinstance(val, (list, tuple, np.ndarray)):
@@ -177,6 +192,46 @@ class Oracle:
                           self._p(actions), None if gr is None else self._p(gr), C.c_uint32(seed),
                           self._p(obs), self._p(states), self._p(rew), self._p(terms))
         return obs, states, rew, terms
+
+    def new_dr_counters(self, N):
+        return np.zeros((N, DR_CNT), np.int64)
+
+    def step_dr(self, phys, task, cnt, drc, actions_raw, clip_actions=1.0, goal_rand=None, seed=0):
+        """lmo_step with domain randomisation; returns obs (noisy, unclipped), states, rew, terms, the clamped noisy actions and the
+        sampled physics attributes (N x 30: max efforts 12, max velocities 12, gravity 3, base force 3)."""
+        N = phys.shape[0]
+        a = self._arr(actions_raw, (N, 12)); gr = None if goal_rand is None else self._arr(goal_rand, (N, 3))
+        assert drc.dtype == np.int64 and drc.shape == (N, DR_CNT)
+        obs = np.zeros((N, self._ep.num_obs), self.dtype); states = np.zeros((N, 93), self.dtype)
+        rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype); used = np.zeros((N, 12), self.dtype); phd = np.zeros((N, 30), self.dtype)
+        cl = C.c_double(clip_actions) if self.dtype == np.float64 else C.c_float(clip_actions)
+        self.lib.lmo_step_dr(C.byref(self.model), C.byref(self.params), C.c_int(N), self._p(phys), self._p(task), self._p(cnt), self._p(drc),
+                             self._p(a), cl, None if gr is None else self._p(gr), C.c_uint32(seed),
+                             self._p(obs), self._p(states), self._p(rew), self._p(terms), self._p(used), self._p(phd))
+        return obs, states, rew, terms, used, phd
+
+    def dr_noise(self, on_reset, on_interval, seed, stream, buf, reset_flags, counter, corr_key, step_key):
+        """randomize.py:212-306 on a float buffer (in place); on_reset / on_interval are DRChannel-like objects or None."""
+        def ch(c):
+            if c is None:
+                return None
+            x = LmoDrChannel(); x.enabled, x.operation, x.distribution, x.interval = int(c.enabled), int(c.operation), int(c.distribution), int(c.interval)
+            for k in range(3):
+                x.p0[k] = float(c.p0[k]); x.p1[k] = float(c.p1[k])
+            return x
+        r, i = ch(on_reset), ch(on_interval)
+        N, D = buf.shape
+        assert buf.dtype == self.dtype and buf.flags.c_contiguous
+        for a in (reset_flags, counter, corr_key, step_key):
+            assert a.dtype == np.int64 and a.shape == (N,)
+        self.lib.lmo_dr_noise(None if r is None else C.byref(r), None if i is None else C.byref(i), C.c_uint32(seed), C.c_uint32(stream),
+                              C.c_int(N), C.c_int(D), self._p(buf), self._p(reset_flags), self._p(counter), self._p(corr_key), self._p(step_key))
+
+    def dr_sample(self, seed, stream, env, key, idx, dist, p0, p1):
+        f = self.lib.lmo_dr_sample
+        rt = C.c_double if self.dtype == np.float64 else C.c_float
+        f.restype = rt
+        return float(f(C.c_uint32(seed), C.c_uint32(stream), C.c_uint32(env), C.c_uint32(key), C.c_uint32(idx), C.c_int(dist), rt(p0), rt(p1)))
 
     def hash_uniform3(self, seed, env, episode):
         u = np.zeros(3, self.dtype)

@@ -333,3 +333,43 @@ def test_blowup_guard_forces_reset(robot_model, engine_cls):
     keep = [i for i in range(N) if i not in (5, 9)]
     assert torch.equal(o1[0][keep], o2[0][keep]) and torch.equal(o1[3][keep], o2[3][keep])
     for e in (e1, e2): e.close()
+
+
+def test_domain_randomisation_step_parity(robot_model, engine_cls, oracle_cls):
+    """lm_step on a randomised engine (k_step_dr: action noise, per-env gravity / base force / max effort / max velocity,
+    observation noise, all in the one launch) against the oracle's lmo_step_dr with the same counter-based random stream."""
+    from test_oracle_dr import yaml_like_dr
+    ep = yaml_like_dr(); N = 256
+    o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N, seed=21)
+    rng = np.random.default_rng(8)
+    phys, task, cnt = o.new_state(N); drc = o.new_dr_counters(N)
+    bad_total = 0
+    for t in range(6):
+        eng.set_phys_env_major(phys); eng.set_task_env_major(task); eng.set_cnt_env_major(cnt)
+        eng.dr_cnt.copy_(torch.as_tensor(np.ascontiguousarray(drc.T), device="cuda"))
+        act = rng.uniform(-1.2, 1.2, size=(N, 12)).astype(np.float32)
+        obs, states, rew, terms, used, phd = o.step_dr(phys, task, cnt, drc, act.astype(np.float64), clip_actions=1.0, seed=21)
+        out = outs(N); eng.step(torch.as_tensor(act, device="cuda"), None, *out); torch.cuda.synchronize()
+        gobs, gst, grew, grs, gex = [x.cpu().numpy() for x in out]
+        assert np.array_equal(eng.dr_cnt.cpu().numpy().T, drc)
+        assert np.abs(eng.dr_phys.cpu().numpy().T - phd).max() < 2e-5 * 10          # sampled attributes (forces up to ~20 N)
+        gt = eng.get_task_env_major()
+        assert np.abs(gt[:, 0:12] - used).max() < 1e-5                               # the clamped noisy actions the task saw
+        d = np.abs(gobs - np.clip(obs, -5, 5)).max(1)
+        bad = d > 5e-3; bad_total += int(bad.sum()); ok = ~bad
+        assert np.median(d) < 3e-4
+        assert np.abs(grew[ok] - rew[ok]).max() < 5e-3 * max(1.0, np.abs(rew).max())
+        assert np.abs(eng.obs_buf.cpu().numpy()[ok] - obs[ok]).max() < 5e-3          # task.obs_buf carries the noise too (in place)
+    assert bad_total <= 0.02 * 6 * N, bad_total
+    # obs noise really is there: the same engine without the two observation channels
+    ep2 = yaml_like_dr(); ep2.dr[0].enabled = 0; ep2.dr[1].enabled = 0
+    e1 = engine_cls(robot_model, [ep], N, seed=5); e2 = engine_cls(robot_model, [ep2], N, seed=5)
+    a = torch.as_tensor(rng.uniform(-1, 1, size=(N, 12)).astype(np.float32), device="cuda")
+    for t in range(3):
+        o1, o2 = outs(N), outs(N); e1.step(a, None, *o1); e2.step(a, None, *o2)
+    torch.cuda.synchronize()
+    dn = (o1[0] - o2[0]).cpu().numpy()
+    assert torch.equal(e1.state, e2.state) and 0.015 < dn.std() < 0.025
+    with pytest.raises(RuntimeError):
+        e1.post_physics(a, *outs(N))
+    for e in (eng, e1, e2): e.close()

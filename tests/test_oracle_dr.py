@@ -1,0 +1,140 @@
+"""Domain randomisation in the oracle.
+
+* lmo_dr_noise is pinned to the reference's own Randomizer.apply_observations_randomization / apply_actions_randomization
+  (utils/domain_randomization/randomize.py:212-306) through tests/golden/dr_noise.npz: degenerate distributions (std 0, low == high)
+  leave exactly the structure - counters, reset handling, correlated-then-uncorrelated order, additive / scaling.
+* The random stream itself is this repo's (counter-based hash): its moments, independence across keys and determinism are checked here.
+* The physics attributes (gravity, base force, max efforts, max joint velocities) are sampled by omni.replicator.isaac in the
+  reference (absent, closed): their semantics are this repo's specification - parity unpinned - checked for
+  self-consistency (ranges, hold intervals, effect on the dynamics)."""
+import os
+
+import numpy as np
+import pytest
+
+from locomanipulationrl_amd.engine_config import (DR_ACT_INTERVAL, DR_ACT_RESET, DR_BASE_FORCE, DR_DISTRIBUTIONS, DR_GRAVITY, DR_MAX_EFFORT,
+                                                  DR_MAX_VELOCITY, DR_OBS_INTERVAL, DR_OBS_RESET, DR_OPERATIONS, DRChannel, loco_params)
+from oracle.lmo import Oracle
+from conftest import GOLDEN
+
+CASES = [   # must match tools/gen_golden.py DR_NOISE_CASES
+    (("additive", "gaussian", [0.25, 0.0]), (1, "additive", "gaussian", [0.5, 0.0])),
+    (("additive", "gaussian", [-0.125, 0.0]), (3, "scaling", "uniform", [1.5, 1.5])),
+    (("scaling", "uniform", [0.75, 0.75]), (4, "additive", "normal", [2.0, 0.0])),
+    (None, (2, "additive", "gaussian", [1.0, 0.0])),
+    (("scaling", "loguniform", [2.0, 2.0]), None),
+]
+
+
+def channel(op, dist, params, interval=0):
+    return DRChannel(enabled=1, operation=DR_OPERATIONS[op], distribution=DR_DISTRIBUTIONS[dist], interval=interval,
+                     p0=[params[0]] * 3, p1=[params[1]] * 3)
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+@pytest.mark.parametrize("kind", ["observations", "actions"])
+def test_noise_structure_against_reference_randomizer(robot_model, ci, kind):
+    g = np.load(os.path.join(GOLDEN, "dr_noise.npz"))
+    o = Oracle(robot_model, loco_params())
+    r, i = CASES[ci]
+    on_reset = None if r is None else channel(*r)
+    on_interval = None if i is None else channel(i[1], i[2], i[3], interval=i[0])
+    X, RF, Y, CT = (g[f"c{ci}_{kind}_{k}"] for k in ("in", "reset", "out", "counter"))
+    T, N, D = X.shape
+    counter = np.zeros(N, np.int64); episode = np.zeros(N, np.int64)
+    for t in range(T):
+        buf = X[t].astype(np.float64).copy(); rf = RF[t].astype(np.int64)
+        episode += rf                                   # the correlated noise is redrawn exactly when the flag is set
+        o.dr_noise(on_reset, on_interval, 5, 0, buf, rf, counter, episode.copy(), np.full(N, t, np.int64))
+        assert np.array_equal(counter, CT[t]), (t, counter, CT[t])
+        assert np.abs(buf - Y[t]).max() < 2e-6, t
+
+
+def test_sampler_moments_and_determinism(robot_model):
+    o = Oracle(robot_model, loco_params())
+    z = np.array([o.dr_sample(9, 1, e, k, 3, 0, 0.5, 2.0) for e in range(200) for k in range(100)])
+    assert abs(z.mean() - 0.5) < 0.05 and abs(z.std() - 2.0) < 0.05
+    zz = (z - 0.5) / 2.0
+    assert abs((zz ** 3).mean()) < 0.06 and abs((zz ** 4).mean() - 3.0) < 0.15                    # normal skewness / kurtosis
+    u = np.array([o.dr_sample(9, 2, e, k, 0, 1, -1.0, 3.0) for e in range(100) for k in range(100)])
+    assert u.min() >= -1.0 and u.max() < 3.0 and abs(u.mean() - 1.0) < 0.05 and abs(u.var() - 16 / 12) < 0.05
+    lu = np.array([o.dr_sample(9, 2, e, 0, 0, 2, 0.1, 10.0) for e in range(4000)])
+    assert lu.min() >= 0.1 and lu.max() <= 10.0 and abs(np.log(lu).mean()) < 0.1
+    # independence across stream / key / index / env: neighbouring samples are uncorrelated
+    a = np.array([[o.dr_sample(9, s, e, 7, j, 0, 0.0, 1.0) for e in range(2000)] for s, j in ((1, 0), (1, 1), (2, 0))])
+    c = np.corrcoef(a)
+    assert np.abs(c - np.eye(3)).max() < 0.06
+    assert o.dr_sample(9, 1, 5, 7, 3, 0, 0.0, 1.0) == o.dr_sample(9, 1, 5, 7, 3, 0, 0.0, 1.0)
+    assert o.dr_sample(9, 1, 5, 7, 3, 0, 0.0, 1.0) != o.dr_sample(10, 1, 5, 7, 3, 0, 0.0, 1.0)
+
+
+def yaml_like_dr(**over):
+    """The randomisation block of cfg/task/QuadrupedPoseControl.yaml:116-173."""
+    dr = [DRChannel() for _ in range(8)]
+    dr[DR_OBS_RESET] = channel("additive", "gaussian", [0.0, 0.001]); dr[DR_OBS_INTERVAL] = channel("additive", "gaussian", [0.0, 0.02], 1)
+    dr[DR_ACT_RESET] = channel("additive", "gaussian", [0.0, 0.015]); dr[DR_ACT_INTERVAL] = channel("additive", "gaussian", [0.0, 0.01], 1)
+    dr[DR_GRAVITY] = DRChannel(1, DR_OPERATIONS["additive"], 0, 400, [0.0, 0.0, 0.0], [0.1, 0.1, 0.5])
+    dr[DR_BASE_FORCE] = DRChannel(1, DR_OPERATIONS["direct"], 0, 1, [0.0, 0.0, 0.0], [5.0, 5.0, 5.0])
+    dr[DR_MAX_VELOCITY] = channel("scaling", "uniform", [0.95, 1.05], 1)
+    dr[DR_MAX_EFFORT] = channel("scaling", "uniform", [0.7, 0.9], 1)
+    return loco_params(dr_enabled=1, dr_min_frequency=400, dr=dr, **over)
+
+
+def test_step_dr_semantics(robot_model):
+    ep = yaml_like_dr(); N = 64
+    o = Oracle(robot_model, ep); o0 = Oracle(robot_model, loco_params())
+    phys, task, cnt = o.new_state(N); drc = o.new_dr_counters(N)
+    p0, t0, c0 = o0.new_state(N)
+    rng = np.random.default_rng(3)
+    grav, force = [], []
+    for t in range(6):
+        act = rng.uniform(-1.3, 1.3, size=(N, 12))
+        obs, states, rew, terms, used, phd = o.step_dr(phys, task, cnt, drc, act, clip_actions=1.0, seed=11)
+        assert np.abs(used).max() <= 1.0                                     # noise first, clamp second (vec_env_rlgames.py:56-60)
+        inner = np.abs(act) < 0.9
+        d = (used - act)[inner]
+        assert 0.005 < d.std() < 0.04 and np.abs(d).max() < 0.12             # sqrt(0.015^2 + 0.01^2) = 0.018
+        assert (phd[:, :12] >= 0.7 * 1.5 - 1e-9).all() and (phd[:, :12] <= 0.9 * 1.5 + 1e-9).all()
+        assert (phd[:, 12:24] >= 0.95 * ep.max_joint_vel - 1e-9).all() and (phd[:, 12:24] <= 1.05 * ep.max_joint_vel + 1e-9).all()
+        grav.append(phd[:, 24:27].copy()); force.append(phd[:, 27:30].copy())
+        assert np.isfinite(obs).all() and np.isfinite(rew).all()
+        assert (drc[:, 2] == t + 1).all() and (drc[:, 3] == t + 1).all()
+    grav, force = np.array(grav), np.array(force)
+    assert np.abs(grav - grav[0]).max() == 0                                 # gravity held for its 400-step interval
+    assert abs(grav[0][:, 2].mean() + 9.81) < 0.25 and 0.3 < grav[0][:, 2].std() < 0.7 and 0.05 < grav[0][:, 0].std() < 0.15
+    assert np.abs(force[1] - force[0]).min() > 0 and 4.0 < force.std() < 6.0  # a fresh base force every control step
+    # observation noise: same trajectory without it (obs do not feed back) differs by N(0, 0.001^2 + 0.02^2)
+    ep2 = yaml_like_dr(); ep2.dr[DR_OBS_RESET].enabled = 0; ep2.dr[DR_OBS_INTERVAL].enabled = 0
+    oa, ob = Oracle(robot_model, ep), Oracle(robot_model, ep2)
+    sa, sb = oa.new_state(N), ob.new_state(N); da, db = oa.new_dr_counters(N), ob.new_dr_counters(N)
+    for t in range(3):
+        act = rng.uniform(-1, 1, size=(N, 12))
+        xa = oa.step_dr(*sa, da, act, seed=4); xb = ob.step_dr(*sb, db, act, seed=4)
+        assert np.array_equal(sa[0], sb[0]) and np.array_equal(xa[2], xb[2])  # identical physics and rewards
+        dn = xa[0] - xb[0]
+        assert 0.015 < dn.std() < 0.025 and abs(dn.mean()) < 0.002
+    # DR with every channel disabled == the plain step
+    ep3 = loco_params(dr_enabled=1)
+    oc = Oracle(robot_model, ep3); s3 = oc.new_state(8); d3 = oc.new_dr_counters(8); s4 = o0.new_state(8)
+    act = rng.uniform(-1, 1, size=(8, 12))
+    x3 = oc.step_dr(*s3, d3, act, seed=2); x4 = o0.step(*s4, act, seed=2)
+    assert np.array_equal(x3[0], x4[0]) and np.array_equal(s3[0], s4[0])
+
+
+def test_external_force_and_gravity_enter_the_dynamics(robot_model):
+    """Free flight (robot lifted off the ground, zero drive): a constant base force F accelerates the total mass by F / m, and a
+    randomised gravity vector is the acceleration of the centre of mass."""
+    dr = [DRChannel() for _ in range(8)]
+    dr[DR_BASE_FORCE] = DRChannel(1, DR_OPERATIONS["direct"], 0, 1, [3.0, -2.0, 1.0], [0.0, 0.0, 0.0])
+    dr[DR_GRAVITY] = DRChannel(1, DR_OPERATIONS["additive"], 0, 1, [0.5, 0.0, 0.81], [0.0, 0.0, 0.0])
+    ep = loco_params(dr_enabled=1, dr=dr, kd=0.0, substeps=1, init_base_pos=[0.0, 0.0, 1.0], max_episode=10000, h_base=-10, h_knee=-10, h_corner=-10)
+    o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(1); drc = o.new_dr_counters(1)
+    o.step_dr(phys, task, cnt, drc, np.zeros((1, 12)), seed=1)
+    v1 = phys[0, 7:10].copy()
+    o.step_dr(phys, task, cnt, drc, np.zeros((1, 12)), seed=1)
+    a = (phys[0, 7:10] - v1) / ep.dt
+    m = float(np.sum(robot_model.mass))
+    # the hub's acceleration equals the COM's up to internal joint motion (joints are free: kd 0), so compare loosely
+    expect = np.array([0.5, 0.0, -9.0]) + np.array([3.0, -2.0, 1.0]) / m
+    assert np.abs(a - expect).max() < 0.35 * np.abs(expect).max(), (a, expect)

@@ -506,6 +506,51 @@ def gen_cotrain(kind, N=32, T=30, seed=13):
     return out
 
 
+# ----------------------------------------------------------------------------- domain randomisation noise (f-3)
+DR_NOISE_CASES = [   # (on_reset, on_interval) entries in the YAML schema of cfg/task/QuadrupedPoseControl.yaml:116-135; std 0 / lo == hi
+    ({"operation": "additive", "distribution": "gaussian", "distribution_parameters": [0.25, 0.0]},
+     {"frequency_interval": 1, "operation": "additive", "distribution": "gaussian", "distribution_parameters": [0.5, 0.0]}),
+    ({"operation": "additive", "distribution": "gaussian", "distribution_parameters": [-0.125, 0.0]},
+     {"frequency_interval": 3, "operation": "scaling", "distribution": "uniform", "distribution_parameters": [1.5, 1.5]}),
+    ({"operation": "scaling", "distribution": "uniform", "distribution_parameters": [0.75, 0.75]},
+     {"frequency_interval": 4, "operation": "additive", "distribution": "normal", "distribution_parameters": [2.0, 0.0]}),
+    (None, {"frequency_interval": 2, "operation": "additive", "distribution": "gaussian", "distribution_parameters": [1.0, 0.0]}),
+    ({"operation": "scaling", "distribution": "loguniform", "distribution_parameters": [2.0, 2.0]}, None),
+]
+
+
+def gen_dr_noise(seed=17, N=16, T=24):
+    """The reference's own Randomizer.apply_observations_randomization / apply_actions_randomization (randomize.py:212-306) with
+    degenerate distributions (std 0, low == high): what is left is the structure - per-env counters, reset handling, the order
+    correlated -> uncorrelated, additive / scaling - which is what the engine must reproduce; its random stream is its own."""
+    from utils.domain_randomization.randomize import Randomizer
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for ci, (on_reset, on_interval) in enumerate(DR_NOISE_CASES):
+        for kind, D in (("observations", 9), ("actions", 12)):
+            params = {}
+            if on_reset is not None: params["on_reset"] = dict(on_reset)
+            if on_interval is not None: params["on_interval"] = dict(on_interval)
+            task_cfg = {"env": {"numEnvs": N}, "domain_randomization": {"randomize": True, "min_frequency": 1,
+                        "randomization_params": {kind: params}}}
+            r = Randomizer(types.SimpleNamespace(task_config=task_cfg, config={"rl_device": "cpu", "seed": 0}))
+            task = types.SimpleNamespace(num_observations=D, num_actions=D, randomize_observations=False, randomize_actions=False)
+            (r._set_up_observations_randomization if kind == "observations" else r._set_up_actions_randomization)(task)
+            assert task.randomize_observations or task.randomize_actions
+            ins, flags, outs, counters = [], [], [], []
+            for t in range(T):
+                buf = torch.randn(N, D, generator=g)
+                rf = torch.ones(N, dtype=torch.long) if t == 0 else (torch.rand(N, generator=g) < 0.2).long()
+                ins.append(buf.clone()); flags.append(rf.clone())
+                fn = r.apply_observations_randomization if kind == "observations" else r.apply_actions_randomization
+                o = fn(buf, rf) if kind == "observations" else fn(actions=buf, reset_buf=rf)
+                outs.append(o.clone())
+                counters.append((r._observations_counter_buffer if kind == "observations" else r._actions_counter_buffer).clone().long())
+            out[f"c{ci}_{kind}_in"] = torch.stack(ins).numpy(); out[f"c{ci}_{kind}_reset"] = torch.stack(flags).numpy()
+            out[f"c{ci}_{kind}_out"] = torch.stack(outs).numpy(); out[f"c{ci}_{kind}_counter"] = torch.stack(counters).numpy()
+    return out
+
+
 def gen_math(seed=3, N=64):
     from utils.math import (inverse_rotate_orientations, inverse_transform_vectors, rand_quaternions,
                             rotate_orientations, transform_vectors)
@@ -605,6 +650,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
         print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "rew", "extras")}, "resets/step", d["reset_buf"].sum(1)[:8],
               "max consec", d["consecutive_successes"].max(), "bonus steps", int((d["rew"] > 300).sum()), "counters", d["counters"])
+    np.savez_compressed(os.path.join(OUT, "dr_noise.npz"), **gen_dr_noise())
     np.savez_compressed(os.path.join(OUT, "math.npz"), **gen_math())
     np.savez_compressed(os.path.join(OUT, "take_action.npz"), **gen_take_action())
     np.savez_compressed(os.path.join(OUT, "gnn.npz"), **gen_gnn())
