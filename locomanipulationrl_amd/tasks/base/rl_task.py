@@ -25,17 +25,6 @@ CC_EXTRAS_KEYS = ["env/rewards/mechanical_power_penalty", "env/rewards/position_
                   "env/rewards/rot_dist_decreasing_reward"]                                      # …custom_controller.py:629-631
 
 
-class _InertRandomizer:
-    """Domain randomisation is disabled in every task YAML on this path (randomize: False)."""
-    randomize = False
-
-    def apply_actions_randomization(self, actions, reset_buf):
-        return actions
-
-    def apply_observations_randomization(self, observations, reset_buf):
-        return observations
-
-
 class RLTask:
     # sizes of the task family on this path
     _num_actions = 12
@@ -60,9 +49,13 @@ class RLTask:
         self.clip_actions = self._task_cfg["env"].get("clipActions", np.inf)
         self.control_frequency_inv = self._task_cfg["env"].get("controlFrequencyInv", 1)
         self._time_inv = self._dt * self.control_frequency_inv
-        self._dr_randomizer = _InertRandomizer()
+        from ...utils.domain_randomization.randomize import Randomizer
+        self._dr_randomizer = Randomizer(self._sim_config)          # rl_task.py:69-73
         self.randomize_actions = False
         self.randomize_observations = False
+        if self._dr_randomizer.randomize:          # the reference does this in set_up_scene / post_reset (quadruped_pose_control.py:181-198)
+            self._dr_randomizer.apply_on_startup_domain_randomization(self)
+            self._dr_randomizer.set_up_domain_randomization(self)
         self._num_agents = 1
         self.action_space = Box(np.ones(self.num_actions, dtype=np.float32) * -1.0, np.ones(self.num_actions, dtype=np.float32) * 1.0)
         self.observation_space = Box(np.ones(self.num_observations, dtype=np.float32) * -np.inf, np.ones(self.num_observations, dtype=np.float32) * np.inf)
@@ -168,6 +161,8 @@ class RLTask:
 
     # staged form (scripts/random_policy.py:57-61)
     def pre_physics_step(self, actions: torch.Tensor) -> None:
+        if self._dr_randomizer.randomize:
+            raise NotImplementedError("domain randomisation is sampled inside the fused lm_step launch; use env.step() when randomize is True")
         if getattr(self, "custom_controller", False):
             raise NotImplementedError("the custom-controller tasks run their physics inside pre_physics_step in the reference "
                                       "(…custom_controller.py:285-296); use env.step() (fused) for them")

@@ -117,6 +117,7 @@ class _QuadrupedTask(RLTask):
                         power_scale=float(self.mechanical_power_penalty_scale), target_err_scale=float(self.position_target_error_penalty_scale),
                         rot_dec_scale=float(self.rot_dist_decreasing_reward_scale), rot_dec_thresh=float(self.no_rot_dist_decreasing_reward_thresh),
                         cc_update_last_tgt=int(self.update_last_targets))
+        base.update(self._dr_randomizer.engine_dr())
         base.update(kw)
         return EngineParams(**base)
 

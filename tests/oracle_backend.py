@@ -23,6 +23,7 @@ class OracleEngine:
         self.obs_buf = torch.zeros((self.N, self.num_obs)); self.states_buf = torch.zeros((self.N, 93)); self.rew_buf = torch.zeros(self.N)
         self.extras_buf = torch.zeros(13); self.terms = torch.zeros((11, self.N)); self.stats_i64 = torch.zeros(6, dtype=torch.int64)
         self._sr = [0.0, 0.0, 0.0]
+        self.drc = o.new_dr_counters(self.N); self.dr_enabled = bool(self.params[0].dr_enabled)
         self._sync_out()
 
     def _halves(self):
@@ -62,14 +63,20 @@ class OracleEngine:
 
     def step(self, actions, goal_rand=None, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
         self._sync_in()
-        a = np.clip(actions.detach().cpu().numpy().astype(np.float64), -self.clip_actions, self.clip_actions)
+        raw = actions.detach().cpu().numpy().astype(np.float64)
+        a = np.clip(raw, -self.clip_actions, self.clip_actions)
         gr = None if goal_rand is None else goal_rand.detach().cpu().numpy().astype(np.float64)
         obs = np.zeros((self.N, self.num_obs)); states = np.zeros((self.N, 93)); rew = np.zeros(self.N); terms = np.zeros((self.N, 11))
         for o, sl in self._halves():
             ph, tk, ct = self.phys[sl].copy(), self.task[sl].copy(), self.cntv[sl].copy()
             # env ids feed the hash RNG: the oracle numbers envs from 0 inside each call, so sample goals here for parity
             g = gr[sl] if gr is not None else np.stack([o.hash_uniform3(self.seed, e, int(self.cntv[e, 5])) for e in range(sl.start, sl.stop)])
-            ob, st, rw, tr = o.step(ph, tk, ct, a[sl], goal_rand=g, seed=self.seed)
+            if self.dr_enabled:
+                dc = self.drc[sl].copy()
+                ob, st, rw, tr, _, _ = o.step_dr(ph, tk, ct, dc, raw[sl], clip_actions=self.clip_actions, goal_rand=g, seed=self.seed)
+                self.drc[sl] = dc
+            else:
+                ob, st, rw, tr = o.step(ph, tk, ct, a[sl], goal_rand=g, seed=self.seed)
             self.phys[sl], self.task[sl], self.cntv[sl] = ph, tk, ct
             obs[sl], states[sl], rew[sl], terms[sl] = ob, st, rw, tr
         self._finish(obs, states, rew, terms, (out_obs, out_states, out_rew, out_resets, out_extras))
