@@ -7,6 +7,7 @@
  */
 #ifndef LM_POLICY_H
 #define LM_POLICY_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -30,6 +31,32 @@ int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean
  * lm_mlp_param_count() is its length.  Outputs as lm_gnn_forward (mean in the env's action order). */
 int lm_mlp_param_count(void);
 int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream);
+
+/* ---- fused rollout: policy forward -> gaussian action sampling -> lm_step, T times, as ONE hipGraph launch.
+ * Replaces the per-step Python of the reference's trainer loop (skrl SequentialTrainer / scripts/random_policy.py:52-61:
+ * agent.act -> env.step -> agent.record_transition) for the duration of a rollout, during which the policy is constant. */
+struct lm_engine;
+typedef struct lm_rollout lm_rollout;
+enum { LM_POLICY_MLP = 0, LM_POLICY_GNN = 1 };
+
+/* Gaussian policy sampling (skrl GaussianMixin.act): actions = mean + exp(log_std) * eps, logp = sum_j log N(actions_j; mean_j, std_j).
+ * eps is a counter-based normal keyed by (seed, env, episode_count, progress_buf) read from the engine's counters
+ * (cnt = lm_ptr(h, LM_PTR_CNT)), so no generator state is kept and no step repeats a draw.
+ *   mean device [n_envs][12], log_std device [12], actions device [n_envs][12] (not clamped: lm_step clamps), logp device [n_envs] */
+int lm_sample_actions(const float* mean, const float* log_std, const int64_t* cnt, int n_envs, uint32_t seed,
+                      float* actions, float* logp, void* stream);
+
+/* Plan a rollout of T steps on `env` (64-wide observations).  All buffers are device memory owned by the caller and must stay valid:
+ *   obs [T+1][N][64]   obs[0] = the current (clipped) observations on entry; obs[t+1] = those returned by step t
+ *   actions [T][N][12], logp [T][N], values [T+1][N] (value head output; values[T] bootstraps), rewards [T][N], dones int64 [T][N],
+ *   extras [T][LM_NUM_EXTRAS] (may be NULL)
+ *   policy_params / log_std: device blocks read at run time (update them in place between runs) */
+int lm_rollout_create(lm_rollout** out, struct lm_engine* env, int policy, const float* policy_params, const float* log_std, int T,
+                      uint32_t noise_seed, float* obs, float* actions, float* logp, float* values, float* rewards, int64_t* dones,
+                      float* extras);
+/* Enqueue the rollout on `stream`: use_graph != 0 replays a hipGraph captured on first use (one launch), 0 enqueues the 4T+1 kernels. */
+int lm_rollout_run(lm_rollout* r, int use_graph, void* stream);
+int lm_rollout_destroy(lm_rollout* r);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/lm_policy.h"
+#include "../../include/lm_engine.h"
+#include <new>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -275,6 +277,109 @@ int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean
   int blocks = (batch + GNN_SAMPLES - 1) / GNN_SAMPLES;
   hipLaunchKernelGGL(k_gnn_forward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, obs, batch, params, mean, value);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+
+// ------------------------------------------------------------------------------------------------ fused rollout (f-2)
+__device__ __forceinline__ uint32_t ro_mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+// standard normal from the same counter-based generator as the engine's domain randomisation (lm_engine.hip dr_sample, stream 9)
+__device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
+  uint32_t base = ro_mix32(seed ^ ro_mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ ro_mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ ro_mix32(9U * 0x27D4EB2FU + 0x632BE5ABU));
+  uint32_t r1 = ro_mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = ro_mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__global__ void __launch_bounds__(256) k_sample_actions(const float* __restrict__ mean, const float* __restrict__ log_std, const int64_t* __restrict__ cnt,
+                                                        int N, uint32_t seed, float* __restrict__ actions, float* __restrict__ logp) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  // (episode_count, progress_buf) identifies the env-step: progress restarts at every reset and the episode count moves on
+  const uint32_t key = ((uint32_t)cnt[5 * (size_t)N + env] << 16) + (uint32_t)cnt[4 * (size_t)N + env];
+  float lp = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    const float ls = log_std[j], eps = ro_normal(seed, (uint32_t)env, key, (uint32_t)j);
+    actions[(size_t)env * 12 + j] = fmaf(expf(ls), eps, mean[(size_t)env * 12 + j]);
+    lp += -0.5f * eps * eps - ls - 0.9189385332046727f;          // log N(a; mean, std) with (a - mean) / std = eps
+  }
+  logp[env] = lp;
+}
+
+struct lm_rollout {
+  lm_engine* env; int policy, T, N; uint32_t seed;
+  const float *params, *log_std; float *obs, *actions, *logp, *values, *rewards, *extras; int64_t* dones;
+  float* mean_tmp; const int64_t* cnt;
+  hipGraphExec_t exec; hipStream_t exec_stream;
+};
+
+static int rollout_enqueue(lm_rollout* r, hipStream_t s) {
+  const size_t N = (size_t)r->N;
+  for (int t = 0; t <= r->T; t++) {
+    const float* ob = r->obs + (size_t)t * N * 64;
+    int rc = (r->policy == LM_POLICY_MLP) ? lm_mlp_forward(ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, s)
+                                          : lm_gnn_forward(ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, s);
+    if (rc) return rc;
+    if (t == r->T) break;                                        // the last forward only bootstraps the value
+    float* act = r->actions + (size_t)t * N * 12;
+    hipLaunchKernelGGL(k_sample_actions, dim3((r->N + 255) / 256), dim3(256), 0, s, r->mean_tmp, r->log_std, r->cnt, r->N, r->seed, act, r->logp + (size_t)t * N);
+    rc = lm_step(r->env, act, nullptr, r->obs + (size_t)(t + 1) * N * 64, nullptr, r->rewards + (size_t)t * N, r->dones + (size_t)t * N,
+                 r->extras ? r->extras + (size_t)t * LM_NUM_EXTRAS : nullptr, s);
+    if (rc) return rc;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int lm_sample_actions(const float* mean, const float* log_std, const int64_t* cnt, int n_envs, uint32_t seed, float* actions, float* logp, void* stream) {
+  if (!mean || !log_std || !cnt || !actions || !logp || n_envs <= 0) return -1;
+  hipLaunchKernelGGL(k_sample_actions, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, log_std, cnt, n_envs, seed, actions, logp);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int lm_rollout_create(lm_rollout** out, lm_engine* env, int policy, const float* policy_params, const float* log_std, int T, uint32_t noise_seed,
+                      float* obs, float* actions, float* logp, float* values, float* rewards, int64_t* dones, float* extras) {
+  if (!out || !env || !policy_params || !log_std || !obs || !actions || !logp || !values || !rewards || !dones || T <= 0) return -1;
+  if (policy != LM_POLICY_MLP && policy != LM_POLICY_GNN) return -1;
+  if (lm_num_obs(env) != 64) return -1;                           // both forward kernels take the 64-wide observation
+  lm_rollout* r = new (std::nothrow) lm_rollout();
+  if (!r) return -3;
+  r->env = env; r->policy = policy; r->T = T; r->N = lm_num_envs(env); r->seed = noise_seed;
+  r->params = policy_params; r->log_std = log_std; r->obs = obs; r->actions = actions; r->logp = logp; r->values = values;
+  r->rewards = rewards; r->dones = dones; r->extras = extras; r->exec = nullptr; r->exec_stream = nullptr;
+  r->cnt = (const int64_t*)lm_ptr(env, LM_PTR_CNT);
+  if (hipMalloc((void**)&r->mean_tmp, (size_t)r->N * 12 * sizeof(float)) != hipSuccess) { delete r; return -2; }
+  *out = r;
+  return 0;
+}
+
+int lm_rollout_run(lm_rollout* r, int use_graph, void* stream) {
+  if (!r) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (!use_graph) return rollout_enqueue(r, s);
+  if (!r->exec) {
+    // capture the 4T+1 launches once; every pointer in them is fixed for the lifetime of the plan
+    hipGraph_t g = nullptr;
+    hipStream_t cs = s;
+    bool own = false;
+    if (cs == nullptr) { if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return -2; own = true; }   // the legacy stream cannot capture
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { if (own) (void)hipStreamDestroy(cs); return -2; }
+    int rc = rollout_enqueue(r, cs);
+    hipError_t e = hipStreamEndCapture(cs, &g);
+    if (own) (void)hipStreamDestroy(cs);
+    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return rc ? rc : -2; }
+    e = hipGraphInstantiate(&r->exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { r->exec = nullptr; return -2; }
+  }
+  return hipGraphLaunch(r->exec, s) == hipSuccess ? 0 : -2;
+}
+
+int lm_rollout_destroy(lm_rollout* r) {
+  if (!r) return 0;
+  if (r->exec) (void)hipGraphExecDestroy(r->exec);
+  if (r->mean_tmp) (void)hipFree(r->mean_tmp);
+  delete r;
+  return 0;
 }
 
 }  // extern "C"

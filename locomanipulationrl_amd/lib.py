@@ -22,7 +22,8 @@ PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_ST
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
            "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_num_obs", "lm_set_seed", "lm_last_error", "lm_version",
-           "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward"]
+           "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward",
+           "lm_sample_actions", "lm_rollout_create", "lm_rollout_run", "lm_rollout_destroy"]
 
 # rows of the SoA float state
 ROW = dict(base_pos=0, base_quat=3, base_lin=7, base_ang=10, q=13, qd=25, plate_pos=37, plate_quat=40, plate_lin=44,
@@ -145,6 +146,10 @@ def load_library() -> C.CDLL:
     lib.lm_set_seed.argtypes = [vp, C.c_uint32]
     lib.lm_gnn_forward.argtypes = [fp, ip, fp, fp, fp, vp]
     lib.lm_mlp_forward.argtypes = [fp, ip, fp, fp, fp, vp]
+    lib.lm_sample_actions.argtypes = [fp, fp, vp, ip, C.c_uint32, fp, fp, vp]
+    lib.lm_rollout_create.argtypes = [C.POINTER(vp), vp, ip, fp, fp, ip, C.c_uint32, fp, fp, fp, fp, fp, vp, fp]
+    lib.lm_rollout_run.argtypes = [vp, ip, vp]
+    lib.lm_rollout_destroy.argtypes = [vp]
     lib.lm_last_error.restype = C.c_char_p
     lib.lm_version.restype = C.c_char_p
     _lib = lib
@@ -308,3 +313,61 @@ class Engine:
 
     def get_cnt_env_major(self):
         return self.cnt.T.contiguous().cpu().numpy()
+
+
+POLICY_MLP, POLICY_GNN = 0, 1
+
+
+class Rollout:
+    """T steps of  policy forward (MFMA) -> gaussian sampling -> lm_step  recorded into rollout buffers and replayed as one hipGraph
+    (include/lm_policy.h).  `packed_params` / `log_std` are device tensors read at run time: refresh them in place
+    between runs.  Buffers: obs (T+1,N,64) with obs[0] = current observations, actions (T,N,12), logp (T,N), values (T+1,N),
+    rewards (T,N), dones int64 (T,N), extras (T,13)."""
+
+    def __init__(self, engine: Engine, policy: int, packed_params, log_std, T: int, noise_seed: int = 0):
+        torch = engine.torch
+        self.engine, self.T, self.N = engine, int(T), engine.num_envs
+        assert engine.num_obs == 64, "the forward kernels take the 64-wide observation"
+        dev = engine.device
+        assert packed_params.is_cuda and packed_params.dtype == torch.float32 and packed_params.is_contiguous()
+        assert log_std.is_cuda and log_std.dtype == torch.float32 and log_std.numel() == 12 and log_std.is_contiguous()
+        n_expected = engine.lib.lm_mlp_param_count() if policy == POLICY_MLP else engine.lib.lm_gnn_param_count()
+        assert packed_params.numel() == n_expected, (packed_params.numel(), n_expected)
+        self.params, self.log_std = packed_params, log_std
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        T, N = self.T, self.N
+        self.obs, self.actions, self.logp, self.values = z(T + 1, N, 64), z(T, N, 12), z(T, N), z(T + 1, N)
+        self.rewards, self.dones, self.extras = z(T, N), z(T, N, dt=torch.int64), z(T, NUM_EXTRAS)
+        self._h = C.c_void_p()
+        p = Engine._p
+        rc = engine.lib.lm_rollout_create(C.byref(self._h), engine._h, int(policy), p(self.params), p(self.log_std), T, C.c_uint32(noise_seed),
+                                          p(self.obs), p(self.actions), p(self.logp), p(self.values), p(self.rewards), p(self.dones), p(self.extras))
+        if rc != 0:
+            raise EngineError(f"lm_rollout_create failed ({rc})")
+
+    def run(self, use_graph: bool = True):
+        rc = self.engine.lib.lm_rollout_run(self._h, 1 if use_graph else 0, self.engine._stream())
+        if rc != 0:
+            raise EngineError(f"lm_rollout_run failed ({rc}): {self.engine.lib.lm_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            self.engine.lib.lm_rollout_destroy(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sample_actions(engine: Engine, mean, log_std, seed: int):
+    """lm_sample_actions: (actions, logp) for the engine's current counters."""
+    torch = engine.torch
+    N = engine.num_envs
+    act = torch.empty((N, 12), device=engine.device); logp = torch.empty((N,), device=engine.device)
+    p = Engine._p
+    rc = engine.lib.lm_sample_actions(p(mean.contiguous()), p(log_std.contiguous()), p(engine.cnt), N, C.c_uint32(seed), p(act), p(logp), engine._stream())
+    if rc != 0:
+        raise EngineError(f"lm_sample_actions failed ({rc})")
+    return act, logp

@@ -139,13 +139,25 @@ class RLTask:
         return (torch.empty((N, self.num_observations), device=dev), torch.empty((N, 93), device=dev), torch.empty((N,), device=dev),
                 torch.empty((N,), dtype=torch.int64, device=dev), torch.empty((13,), device=dev))
 
+    def extras_dict(self, extras) -> Dict[str, torch.Tensor]:
+        """The 13-float extras block of a step as the reference's `extras` dict (quadruped_pose_control.py:560,610,633)."""
+        d = {k: extras[i] for i, k in enumerate(EXTRAS_KEYS)}
+        if self.split_env() is not None:
+            d.update({k: extras[8 + i] for i, k in enumerate(COTRAIN_EXTRAS_KEYS)})
+        if getattr(self, "custom_controller", False):
+            d.update({k: extras[10 + i] for i, k in enumerate(self.cc_extras_keys)})
+        return d
+
+    def make_rollout(self, policy: str, packed_params: torch.Tensor, log_std: torch.Tensor, T: int, noise_seed: int = 0):
+        """A fused T-step rollout (policy forward -> sampling -> step, one hipGraph launch; include/lm_policy.h)."""
+        from ...lib import POLICY_GNN, POLICY_MLP, Rollout
+        if self._goal_rng != "engine":
+            raise NotImplementedError("the fused rollout samples goals with the in-kernel generator (env.goalSampler: engine)")
+        return Rollout(self.engine, {"mlp": POLICY_MLP, "gnn": POLICY_GNN}[policy], packed_params, log_std, T, noise_seed)
+
     def _publish(self, out):
         obs, states, rew, resets, extras = out
-        self.extras = {k: extras[i] for i, k in enumerate(EXTRAS_KEYS)}
-        if self.split_env() is not None:
-            self.extras.update({k: extras[8 + i] for i, k in enumerate(COTRAIN_EXTRAS_KEYS)})
-        if getattr(self, "custom_controller", False):
-            self.extras.update({k: extras[10 + i] for i, k in enumerate(self.cc_extras_keys)})
+        self.extras = self.extras_dict(extras)
         if self.num_states == self.num_observations:
             states = obs
         return obs, states, rew, resets, self.extras

@@ -49,7 +49,8 @@ class RunningStandardScaler:
 
 class PPO:
     def __init__(self, env, model, rollouts=48, learning_epochs=5, mini_batches=1, gamma=0.99, lam=0.95, lr=3e-4, kl_threshold=0.012,
-                 grad_norm_clip=1.0, ratio_clip=0.2, value_clip=0.2, value_loss_scale=1.0, entropy_loss_scale=0.0, hip_inference=True):
+                 grad_norm_clip=1.0, ratio_clip=0.2, value_clip=0.2, value_loss_scale=1.0, entropy_loss_scale=0.0, hip_inference=True,
+                 fused_rollout=True):
         self.env, self.model = env, model
         self.dev = next(model.parameters()).device
         self.N = env.num_envs
@@ -65,6 +66,16 @@ class PPO:
         self.b_obs, self.b_act, self.b_logp = z(self.T, self.N, self.n_obs), z(self.T, self.N, 12), z(self.T, self.N)
         self.b_val, self.b_rew, self.b_done = z(self.T, self.N), z(self.T, self.N), z(self.T, self.N)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # fused rollout: forward -> sampling -> step x T as one hipGraph launch, buffers shared with the update
+        self.rollout = None
+        if self.hip and fused_rollout and hasattr(env, "_task") and hasattr(env._task, "make_rollout"):
+            kind = "gnn" if type(model).__name__ == "GraphPolicy" else "mlp"
+            model.refresh(self.dev, self.obs_scaler.mean.float(), self.obs_scaler.var.float(), self.obs_scaler.eps, self.obs_scaler.clip)
+            self._packed = model._packed.clone(); self._log_std = model.log_std_parameter.detach().clone().float().contiguous()
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self.rollout = env._task.make_rollout(kind, self._packed, self._log_std, self.T, noise_seed=1000 + rank)
+            ro = self.rollout
+            self.b_obs, self.b_act, self.b_logp, self.b_rew = ro.obs[:self.T], ro.actions, ro.logp, ro.rewards
 
     # ------------------------------------------------------------------ policy evaluation
     def _policy(self, obs_raw):
@@ -83,6 +94,15 @@ class PPO:
 
     # ------------------------------------------------------------------ one iteration = T env steps + update
     def collect(self, obs_raw):
+        if self.rollout is not None:
+            ro = self.rollout
+            self.model.refresh(self.dev, self.obs_scaler.mean.float(), self.obs_scaler.var.float(), self.obs_scaler.eps, self.obs_scaler.clip)
+            self._packed.copy_(self.model._packed); self._log_std.copy_(self.model.log_std_parameter.detach())
+            ro.obs[0].copy_(obs_raw)
+            ro.run(use_graph=True)
+            v = self.val_scaler(ro.values.reshape(-1, 1), inverse=True).reshape(self.T + 1, self.N)
+            self.b_val, self.b_done = v[:self.T], ro.dones.float()
+            return ro.obs[self.T], v[self.T], self.env._task.extras_dict(ro.extras[self.T - 1])
         for t in range(self.T):
             mean, log_std, value = self._policy(obs_raw)
             act = mean + log_std.exp() * torch.randn_like(mean)

@@ -128,3 +128,63 @@ def test_mlp_hip_forward_matches_torch(B):
         ref_mean, _, ref_value = m(xn)
     mean, value = mlp_forward_hip(obs, pack_mlp_params(m, mu, var, 1e-8, 5.0))
     assert (mean - ref_mean).abs().max() < 2e-5 and (value - ref_value).abs().max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["mlp", "gnn"])
+def test_fused_rollout_graph_equals_stepwise(policy):
+    """T steps of forward -> sampling -> lm_step as ONE hipGraph launch give bit-identical buffers to the same kernels
+    driven step by step from Python, and to the un-captured enqueue; sampled actions follow N(mean, std) with the stated log-prob."""
+    import math
+    import numpy as np
+    from locomanipulationrl_amd.engine_config import loco_params
+    from locomanipulationrl_amd.lib import Engine, Rollout, POLICY_GNN, POLICY_MLP, sample_actions
+    from locomanipulationrl_amd.model.robot_model import load_model
+    from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params, gnn_forward_hip
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params, mlp_forward_hip
+    torch.manual_seed(3)
+    N, T = 512, 12
+    rm = load_model("quadruped_robot_v2")
+    if policy == "mlp":
+        model = SharedMLP().cuda(); packed = pack_mlp_params(model, None, None).cuda(); fwd = mlp_forward_hip; kind = POLICY_MLP
+    else:
+        model = GraphPolicy().cuda(); packed = pack_gnn_params(model.net, model.mean_layer, model.value_layer).cuda(); fwd = gnn_forward_hip; kind = POLICY_GNN
+    log_std = torch.full((12,), -0.7, device="cuda")
+    engines = [Engine(rm, [loco_params()], N, seed=4) for _ in range(3)]
+    outs0 = []
+    for e in engines:      # the reset step, to have observations to start from
+        o = torch.empty(N, 64, device="cuda"); e.step(torch.zeros(N, 12, device="cuda"), None, o); outs0.append(o)
+    ro_graph = Rollout(engines[0], kind, packed, log_std, T, noise_seed=77); ro_graph.obs[0] = outs0[0]
+    ro_plain = Rollout(engines[1], kind, packed, log_std, T, noise_seed=77); ro_plain.obs[0] = outs0[1]
+    ro_graph.run(use_graph=True); ro_plain.run(use_graph=False)
+    # step-by-step reference on the third engine with the same kernels
+    e = engines[2]; obs = outs0[2]
+    ref = dict(obs=[obs.clone()], act=[], logp=[], val=[], rew=[], done=[])
+    for t in range(T):
+        mean, value = fwd(obs.contiguous(), packed)
+        act, logp = sample_actions(e, mean, log_std, 77)
+        o = torch.empty(N, 64, device="cuda"); r = torch.empty(N, device="cuda"); d = torch.empty(N, dtype=torch.int64, device="cuda")
+        e.step(act, None, o, None, r, d)
+        ref["act"].append(act); ref["logp"].append(logp); ref["val"].append(value.reshape(-1)); ref["rew"].append(r); ref["done"].append(d); ref["obs"].append(o.clone())
+        obs = o
+    _, vlast = fwd(obs.contiguous(), packed); ref["val"].append(vlast.reshape(-1))
+    torch.cuda.synchronize()
+    for ro in (ro_graph, ro_plain):
+        assert torch.equal(ro.obs, torch.stack(ref["obs"])) and torch.equal(ro.actions, torch.stack(ref["act"]))
+        assert torch.equal(ro.logp, torch.stack(ref["logp"])) and torch.equal(ro.values, torch.stack(ref["val"]))
+        assert torch.equal(ro.rewards, torch.stack(ref["rew"])) and torch.equal(ro.dones, torch.stack(ref["done"]))
+    assert torch.equal(engines[0].state, engines[2].state) and torch.equal(engines[0].cnt, engines[2].cnt)
+    # a second replay of the same graph continues the trajectory (fresh noise: the counters moved on)
+    ro_graph.obs[0] = ro_graph.obs[T]; a_prev = ro_graph.actions.clone(); ro_graph.run(use_graph=True); torch.cuda.synchronize()
+    assert not torch.equal(a_prev, ro_graph.actions) and torch.isfinite(ro_graph.obs).all()
+    # sampling statistics and log-prob
+    mean_all = []
+    obs_t = ro_plain.obs[:T].reshape(-1, 64)
+    m, _ = fwd(obs_t.contiguous(), packed)
+    eps = ((ro_plain.actions.reshape(-1, 12) - m) / log_std.exp()).cpu().numpy()
+    assert abs(eps.mean()) < 0.02 and abs(eps.std() - 1.0) < 0.02 and abs((eps ** 4).mean() - 3.0) < 0.2
+    c = np.corrcoef(eps[:, :4].T); assert np.abs(c - np.eye(4)).max() < 0.05
+    lp = (-0.5 * eps ** 2 - log_std.cpu().numpy() - 0.5 * math.log(2 * math.pi)).sum(1)
+    assert np.abs(lp - ro_plain.logp.reshape(-1).cpu().numpy()).max() < 2e-4
+    for r in (ro_graph, ro_plain): r.close()
+    for e in engines: e.close()
