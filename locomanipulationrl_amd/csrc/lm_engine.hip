@@ -48,7 +48,7 @@ struct lm_engine {
   lm_params* d_params;     // [2]
   float* d_table;
   float* d_state; int64_t* d_cnt; int64_t* d_drc; float* d_dr_phys; int dr_enabled;
-  float *d_obs, *d_states, *d_rew, *d_extras, *d_terms, *d_partials;
+  float *d_obs, *d_states, *d_rew, *d_extras, *d_terms; long long* d_acc;
   char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48
   lm_params h_params[2];
 };
@@ -619,7 +619,16 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
 // shared tail: write staged obs / states, reward, counters, per-block partial sums
 LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
 
-struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms, *partials; float *out_obs, *out_states, *out_rew; int64_t* out_resets; };
+struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms; float *out_obs, *out_states, *out_rew; int64_t* out_resets;
+                 long long* acc;          // int64 [16]: fixed-point sums of the 12 per-env terms, first-task shares of goal_reset / reset, -, arrival ticket
+                 char* stats; float* extras; float* out_extras; int split_block; };
+#define ACC_SCALE 1048576.0f      // 2^20: integer accumulation makes the means independent of the arrival order (bitwise reproducible)
+
+LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
+  int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
+  if (num_rst > max_cnt) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
+  ns[0] = num_succ + add_succ; ns[1] = num_rst + add_rst; *rate = sr;
+}
 
 struct DrOut { int64_t* drc; uint32_t seed, dr_step; int64_t rand_buf, reset_key; uint32_t* sKey; };      // sKey: LDS [16][2] {corr key, fire}
 
@@ -691,9 +700,42 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     part[k] = v;
   }
-  if (lane == 0) {
+  // ---- means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps two more
+  // windows for its halves, joint_locomanipulation.py:795-859).  Every wavefront adds its 14 partial sums to int64 accumulators with
+  // relaxed device-scope atomics (returning, so that vmcnt(0) means "performed"), then takes a ticket; the last one to arrive reads
+  // the totals, publishes the extras and clears the accumulators for the next launch.  No fence, no second kernel.
+  {
+    const bool first_task = (int)blockIdx.x < W.split_block;
+    float mine = 0.f, tot0[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) W.partials[(size_t)k * gridDim.x + blockIdx.x] = part[k];      // [k][block]: coalesced for k_finalize
+    for (int k = 0; k < 12; k++) { tot0[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part[k]))); mine = (lane == k) ? tot0[k] : mine; }   // lane 0 holds the sums
+    mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
+    mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
+    long long dummy = 0;
+    if (lane < 14) dummy = __hip_atomic_fetch_add(W.acc + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's atomics (and its stores) have been performed
+    asm volatile("" :: "v"(dummy));
+    int ticket = 0;
+    if (lane == 0) ticket = (int)__hip_atomic_fetch_add(W.acc + 15, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0);
+    if (ticket == (int)gridDim.x - 1) {
+      long long tot = 0;
+      if (lane < 14) tot = __hip_atomic_load(W.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
+      if (lane < 7) { float m = sum / (float)N; W.extras[lane] = m; if (W.out_extras) W.out_extras[lane] = m; }
+      if (lane >= 9 && lane < 12) { float m = sum / (float)N; W.extras[lane + 1] = m; if (W.out_extras) W.out_extras[lane + 1] = m; }      // extras 10..12
+      const float gsf = __shfl(sum, 7), rsf = __shfl(sum, 8), glf = __shfl(sum, 12), rlf = __shfl(sum, 13);
+      if (lane == 0) {
+        int64_t* ns = reinterpret_cast<int64_t*>(W.stats); float* rate = reinterpret_cast<float*>(W.stats + 48);
+        const int64_t gs = (int64_t)(gsf + 0.5f), rs = (int64_t)(rsf + 0.5f), gl = (int64_t)(glf + 0.5f), rl = (int64_t)(rlf + 0.5f);
+        success_window(ns + 0, rate + 0, gs, rs, (int64_t)P->max_reset_counts);
+        success_window(ns + 2, rate + 1, gl, rl, (int64_t)P->max_reset_counts);
+        success_window(ns + 4, rate + 2, gs - gl, rs - rl, (int64_t)P->max_reset_counts);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { W.extras[7 + k] = rate[k]; if (W.out_extras) W.out_extras[7 + k] = rate[k]; }
+      }
+      if (lane < 16) __hip_atomic_store(W.acc + lane, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -939,61 +981,6 @@ __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash); }
   else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash); }
   else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 1>(A, P, sTab, sObs, sSt, sStash); }
-}
-
-// means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps
-// two more windows for its locomotion / manipulation halves, joint_locomanipulation.py:795-859).
-// 256 threads: coalesced loads of the [k][block] partials (all independent, one round trip), fixed-order shuffle + LDS tree
-// -> deterministic sums without a serial dependent-load chain.  split_block = first block of the second task.
-LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
-  int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
-  if (num_rst > max_cnt) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
-  ns[0] = num_succ + add_succ; ns[1] = num_rst + add_rst; *rate = sr;
-}
-__global__ void __launch_bounds__(256) k_finalize(const float* partials, int nblocks, int split_block, int N, const lm_params* P, char* stats,
-                                                  float* extras, float* out_extras) {
-  __shared__ float red[4][16];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  float s[14];
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    float a = 0.f;
-    for (int b = t; b < nblocks; b += 256) a += partials[(size_t)k * nblocks + b];
-    s[k] = a;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {          // custom-controller reward terms
-    float a = 0.f;
-    for (int b = t; b < nblocks; b += 256) a += partials[(size_t)(9 + k) * nblocks + b];
-    s[11 + k] = a;
-  }
-  // first-task (locomotion half) share of the goal-reset / reset counts
-  s[9] = 0.f; s[10] = 0.f;
-  for (int b = t; b < split_block; b += 256) { s[9] += partials[(size_t)7 * nblocks + b]; s[10] += partials[(size_t)8 * nblocks + b]; }
-#pragma unroll
-  for (int k = 0; k < 14; k++) {
-    float a = s[k];
-    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-    if (lane == 0) red[wv][k] = a;
-  }
-  __syncthreads();
-  if (t < 14) {
-    float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    red[0][t] = tot;
-    if (t < 7) { float m = tot / (float)N; extras[t] = m; if (out_extras) out_extras[t] = m; }
-    if (t >= 11) { float m = tot / (float)N; extras[t - 1] = m; if (out_extras) out_extras[t - 1] = m; }     // extras 10..12
-  }
-  __syncthreads();
-  if (t == 0) {
-    int64_t* ns = reinterpret_cast<int64_t*>(stats); float* rate = reinterpret_cast<float*>(stats + 48);
-    const int64_t gs = (int64_t)(red[0][7] + 0.5f), rs = (int64_t)(red[0][8] + 0.5f);
-    const int64_t gl = (int64_t)(red[0][9] + 0.5f), rl = (int64_t)(red[0][10] + 0.5f);
-    success_window(ns + 0, rate + 0, gs, rs, (int64_t)P->max_reset_counts);
-    success_window(ns + 2, rate + 1, gl, rl, (int64_t)P->max_reset_counts);
-    success_window(ns + 4, rate + 2, gs - gl, rs - rl, (int64_t)P->max_reset_counts);
-#pragma unroll
-    for (int k = 0; k < 3; k++) { extras[7 + k] = rate[k]; if (out_extras) out_extras[7 + k] = rate[k]; }
-  }
 }
 
 __global__ void __launch_bounds__(64) k_reset_all(int64_t* cnt, int N) {
@@ -1263,7 +1250,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_rew, N * sizeof(float));
   ALLOC(h->d_extras, 16 * sizeof(float));
   ALLOC(h->d_terms, LM_TERM_ROWS * N * sizeof(float));
-  ALLOC(h->d_partials, (size_t)h->nblocks * NPART * sizeof(float));
+  ALLOC(h->d_acc, 16 * sizeof(long long));
   ALLOC(h->d_stats, 64);
 #undef ALLOC
   HIPCHK(hipMemcpy(h->d_params, h->h_params, 2 * sizeof(lm_params), hipMemcpyHostToDevice));
@@ -1283,7 +1270,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
 
 int lm_destroy(lm_engine* h) {
   if (!h) return LM_OK;
-  void* ptrs[] = {h->d_params, h->d_table, h->d_state, h->d_cnt, h->d_drc, h->d_dr_phys, h->d_obs, h->d_states, h->d_rew, h->d_extras, h->d_terms, h->d_partials, h->d_stats};
+  void* ptrs[] = {h->d_params, h->d_table, h->d_state, h->d_cnt, h->d_drc, h->d_dr_phys, h->d_obs, h->d_states, h->d_rew, h->d_extras, h->d_terms, h->d_acc, h->d_stats};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return LM_OK;
@@ -1292,7 +1279,8 @@ int lm_destroy(lm_engine* h) {
 static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states, float* out_rew, int64_t* out_resets) {
   StepArgs A;
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
-  A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.partials = h->d_partials;
+  A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.acc = h->d_acc;
+  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
   A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
   return A;
@@ -1302,10 +1290,9 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
             int64_t* out_resets, float* out_extras, void* stream) {
   if (!h || !actions) return fail(LM_EINVAL, "lm_step: null handle or actions");
   hipStream_t s = (hipStream_t)stream;
-  StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets);
+  StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   if (h->dr_enabled) hipLaunchKernelGGL(k_step_dr, dim3(h->nblocks), dim3(64), 0, s, A);
   else hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -1315,10 +1302,9 @@ int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* o
   if (!h || !actions) return fail(LM_EINVAL, "lm_post_physics: null handle or actions");
   if (h->dr_enabled) return fail(LM_EINVAL, "lm_post_physics: a randomised engine runs through lm_step only");
   hipStream_t s = (hipStream_t)stream;
-  StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
+  StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   A.skip_reset = 1; A.nsub = 0;
   hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -1334,9 +1320,8 @@ int lm_task_eval(lm_engine* h, const float* readback, const float* actions, floa
                  int64_t* out_resets, float* out_extras, void* stream) {
   if (!h || !readback || !actions) return fail(LM_EINVAL, "lm_task_eval: null argument");
   hipStream_t s = (hipStream_t)stream;
-  StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets);
+  StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   hipLaunchKernelGGL(k_task_eval, dim3(h->nblocks), dim3(64), 0, s, A, readback);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, h->d_partials, h->nblocks, h->split / ENVS_PER_WAVE, h->N, h->d_params, h->d_stats, h->d_extras, out_extras);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }

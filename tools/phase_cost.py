@@ -1,0 +1,31 @@
+"""Where k_step's time goes (4096 envs, loco): the runtime parameters switch phases off, so the differences are phase costs.
+    substeps 4 -> 1 : per-sub-step cost and the fixed part (load, reset, task layer, outputs)
+    pgs_iters 8 -> 0 : the contact solver sweeps;  tau_max -> huge : no saturated joints => the second active-set pass never runs"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from locomanipulationrl_amd.engine_config import loco_params
+from locomanipulationrl_amd.lib import Engine
+from locomanipulationrl_amd.model.robot_model import load_model
+
+
+def run(N, steps=400, warmup=50, **kw):
+    eng = Engine(load_model("quadruped_robot_v2"), [loco_params(**kw)], N, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    pool = [torch.rand(N, 12, device="cuda", generator=g) * 2 - 1 for _ in range(16)]
+    o = (torch.empty(N, 64, device="cuda"), torch.empty(N, 93, device="cuda"), torch.empty(N, device="cuda"),
+         torch.empty(N, dtype=torch.int64, device="cuda"), torch.empty(13, device="cuda"))
+    for t in range(warmup): eng.step(pool[t % 16], None, *o)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in range(steps): eng.step(pool[t % 16], None, *o)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    return dt * 1e6
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    cases = {"default": {}, "pgs0": dict(pgs_iters=0), "nosat": dict(tau_max=1e9), "nosat_pgs0": dict(tau_max=1e9, pgs_iters=0),
+             "sub1": dict(substeps=1), "sub1_nosat_pgs0": dict(substeps=1, tau_max=1e9, pgs_iters=0), "sub8": dict(substeps=8)}
+    res = {k: run(N, **v) for k, v in cases.items()}
+    print(json.dumps({"envs": N, "us_per_step": res}))
