@@ -219,37 +219,41 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // cross blocks X_K = T_i^T B_K towards the other three contacts; lanes take turns, the lane whose turn it is
 // relaxes its three rows, then its three impulse increments are quad-broadcast and every other lane updates c
 // with 9 FMAs.  Identical arithmetic (up to rounding) to row-wise PGS on the dense 12x12 system of the oracle.
-struct PgsData { float Wf[6]; float rW[3]; float X[4][9]; };
+struct PgsData { float Wf[6]; float rW[3]; float X[4][9]; };      // X[K]: this contact's 3x3 block towards contact K (K == own limb: the own block)
 
 template <int K>
-LM_DEV void pgs_cross_blocks(int limb, const SV T[3], const SV B[3], float X[9]) {
+LM_DEV void pgs_cross_blocks(int limb, const SV T[3], const SV B[3], const float Wf[6], float X[9]) {
   SV Bk[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     Bk[s].w = v3(quad_bcast<K>(B[s].w.x), quad_bcast<K>(B[s].w.y), quad_bcast<K>(B[s].w.z));
     Bk[s].v = v3(quad_bcast<K>(B[s].v.x), quad_bcast<K>(B[s].v.y), quad_bcast<K>(B[s].v.z));
   }
-  const float keep = (limb == K) ? 0.f : 1.f;      // the own block is applied through Wf
+  const bool own = (limb == K);
+  const float Wown[9] = {Wf[0], Wf[1], Wf[2], Wf[1], Wf[3], Wf[4], Wf[2], Wf[4], Wf[5]};
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int s = 0; s < 3; s++) X[3 * r + s] = keep * sdot(T[r], Bk[s]);
+    for (int s = 0; s < 3; s++) X[3 * r + s] = own ? Wown[3 * r + s] : sdot(T[r], Bk[s]);
 }
 
+// One Gauss-Seidel turn: contact K relaxes its rows n, t1, t2 in sequence (each row sees the rows before it through the two
+// temporaries t1, t2), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies
+// c += X[K] * d.  Lanes whose turn it is not run the same instructions on their own (discarded) candidates; only `lam` is guarded.
 template <int K>
 LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float lam[3], float c[3]) {
   const bool mine = (limb == K);
-  float ln = fmaxf(0.0f, lam[0] - c[0] * G.rW[0]);
-  float d0 = mine ? (ln - lam[0]) : 0.f;
-  lam[0] += d0; c[0] = fmaf(G.Wf[0], d0, c[0]); c[1] = fmaf(G.Wf[1], d0, c[1]); c[2] = fmaf(G.Wf[2], d0, c[2]);
-  float lim = mu * lam[0];
-  float l1 = fminf(lim, fmaxf(-lim, lam[1] - c[1] * G.rW[1]));
-  float d1 = mine ? (l1 - lam[1]) : 0.f;
-  lam[1] += d1; c[0] = fmaf(G.Wf[1], d1, c[0]); c[1] = fmaf(G.Wf[3], d1, c[1]); c[2] = fmaf(G.Wf[4], d1, c[2]);
-  float l2 = fminf(lim, fmaxf(-lim, lam[2] - c[2] * G.rW[2]));
-  float d2 = mine ? (l2 - lam[2]) : 0.f;
-  lam[2] += d2; c[0] = fmaf(G.Wf[2], d2, c[0]); c[1] = fmaf(G.Wf[4], d2, c[1]); c[2] = fmaf(G.Wf[5], d2, c[2]);
-  float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d1), b2 = quad_bcast<K>(d2);
+  const float ln = fmaxf(0.0f, fmaf(-c[0], G.rW[0], lam[0]));
+  const float d0 = ln - lam[0];
+  const float lim = mu * ln;
+  const float t1 = fmaf(G.Wf[1], d0, c[1]);
+  const float l1 = __builtin_amdgcn_fmed3f(fmaf(-t1, G.rW[1], lam[1]), -lim, lim);
+  const float d1 = l1 - lam[1];
+  const float t2 = fmaf(G.Wf[4], d1, fmaf(G.Wf[2], d0, c[2]));
+  const float l2 = __builtin_amdgcn_fmed3f(fmaf(-t2, G.rW[2], lam[2]), -lim, lim);
+  const float d2 = l2 - lam[2];
+  lam[0] = mine ? ln : lam[0]; lam[1] = mine ? l1 : lam[1]; lam[2] = mine ? l2 : lam[2];
+  const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d1), b2 = quad_bcast<K>(d2);
   const float* X = G.X[K];
   c[0] = fmaf(X[0], b0, fmaf(X[1], b1, fmaf(X[2], b2, c[0])));
   c[1] = fmaf(X[3], b0, fmaf(X[4], b1, fmaf(X[5], b2, c[1])));
@@ -263,8 +267,8 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
   G.Wf[0] = Wl[0] + sdot(T[0], B[0]); G.Wf[1] = Wl[1] + sdot(T[0], B[1]); G.Wf[2] = Wl[2] + sdot(T[0], B[2]);
   G.Wf[3] = Wl[3] + sdot(T[1], B[1]); G.Wf[4] = Wl[4] + sdot(T[1], B[2]); G.Wf[5] = Wl[5] + sdot(T[2], B[2]);
   G.rW[0] = 1.0f / G.Wf[0]; G.rW[1] = 1.0f / G.Wf[3]; G.rW[2] = 1.0f / G.Wf[5];
-  pgs_cross_blocks<0>(limb, T, B, G.X[0]); pgs_cross_blocks<1>(limb, T, B, G.X[1]);
-  pgs_cross_blocks<2>(limb, T, B, G.X[2]); pgs_cross_blocks<3>(limb, T, B, G.X[3]);
+  pgs_cross_blocks<0>(limb, T, B, G.Wf, G.X[0]); pgs_cross_blocks<1>(limb, T, B, G.Wf, G.X[1]);
+  pgs_cross_blocks<2>(limb, T, B, G.Wf, G.X[2]); pgs_cross_blocks<3>(limb, T, B, G.Wf, G.X[3]);
   lam[0] = lam[1] = lam[2] = 0.f;
   float c[3] = {vf[0] + bn, vf[1], vf[2]};
   for (int it = 0; it < iters; it++) {
