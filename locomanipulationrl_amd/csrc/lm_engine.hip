@@ -654,6 +654,34 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS staging writes landed (single wave per block)
   __builtin_amdgcn_wave_barrier();
+  // per-block partial sums (fixed order -> deterministic means)
+  float part[12];
+  bool cnts = active && (limb == 0);
+#pragma unroll
+  for (int k = 0; k < 8; k++) part[k] = cnts ? O.terms[k] : 0.f;
+  part[8] = cnts ? (float)S.reset : 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) part[9 + k] = cnts ? O.terms[8 + k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    float v = part[k];
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    part[k] = v;
+  }
+  // ---- means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps two more
+  // windows for its halves, joint_locomanipulation.py:795-859).  Every wavefront adds its 14 partial sums to int64 accumulators with
+  // relaxed device-scope atomics (returning, so that vmcnt(0) means "performed"), then takes a ticket; the last one to arrive reads
+  // the totals, publishes the extras and clears the accumulators for the next launch.  No fence, no second kernel.
+  long long dummy = 0;
+  {
+    const bool first_task = (int)blockIdx.x < W.split_block;
+    float mine = 0.f, tot0[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { tot0[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part[k]))); mine = (lane == k) ? tot0[k] : mine; }   // lane 0 holds the sums
+    mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
+    mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
+    if (lane < 14) dummy = __hip_atomic_fetch_add(W.acc + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const float clip = P->clip_obs;
   int nenv = min(ENVS_PER_WAVE, N - env0);
   const int NO = P->num_obs;
@@ -690,33 +718,7 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
 #pragma unroll
     for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
   }
-  // per-block partial sums (fixed order -> deterministic means)
-  float part[12];
-  bool cnts = active && (limb == 0);
-#pragma unroll
-  for (int k = 0; k < 8; k++) part[k] = cnts ? O.terms[k] : 0.f;
-  part[8] = cnts ? (float)S.reset : 0.f;
-#pragma unroll
-  for (int k = 0; k < 3; k++) part[9 + k] = cnts ? O.terms[8 + k] : 0.f;
-#pragma unroll
-  for (int k = 0; k < 12; k++) {
-    float v = part[k];
-    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-    part[k] = v;
-  }
-  // ---- means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps two more
-  // windows for its halves, joint_locomanipulation.py:795-859).  Every wavefront adds its 14 partial sums to int64 accumulators with
-  // relaxed device-scope atomics (returning, so that vmcnt(0) means "performed"), then takes a ticket; the last one to arrive reads
-  // the totals, publishes the extras and clears the accumulators for the next launch.  No fence, no second kernel.
   {
-    const bool first_task = (int)blockIdx.x < W.split_block;
-    float mine = 0.f, tot0[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) { tot0[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part[k]))); mine = (lane == k) ? tot0[k] : mine; }   // lane 0 holds the sums
-    mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
-    mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
-    long long dummy = 0;
-    if (lane < 14) dummy = __hip_atomic_fetch_add(W.acc + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's atomics (and its stores) have been performed
     asm volatile("" :: "v"(dummy));
     int ticket = 0;
@@ -748,6 +750,19 @@ LM_DEV void load_table(const float* __restrict__ table, float* sTab, int lane) {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
 }
+// the same in two halves so that the table's round trip overlaps the state loads of the step kernel
+#define TABLE_REGS ((LM_TABLE_FLOATS + 63) / 64)
+struct TableRegs { float v[TABLE_REGS]; };
+LM_DEV void table_fetch(const float* __restrict__ table, int lane, TableRegs& T) {
+#pragma unroll
+  for (int j = 0; j < TABLE_REGS; j++) { int i = lane + 64 * j; T.v[j] = (i < LM_TABLE_FLOATS) ? table[i] : 0.f; }
+}
+LM_DEV void table_commit(const TableRegs& T, float* sTab, int lane) {
+#pragma unroll
+  for (int j = 0; j < TABLE_REGS; j++) { int i = lane + 64 * j; if (i < LM_TABLE_FLOATS) sTab[i] = T.v[j]; }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -762,7 +777,8 @@ struct StepArgs {
 };
 
 template <int MODE, int VAR, int DR>
-LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const float* sTab, float* sObs, float* sSt, float4* sStash) {
+LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float* sTab, float* sObs, float* sSt, float4* sStash) {
+  TableRegs TR; table_fetch(A.table, threadIdx.x, TR);
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
   const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
   const bool active = envr < N; const int env = active ? envr : (N - 1);
@@ -839,6 +855,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, const 
   }
   M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
+  table_commit(TR, sTab, lane);
   float tau_acc[3] = {0.f, 0.f, 0.f}, tgtq[3] = {0.f, 0.f, 0.f}, qda[3] = {0.f, 0.f, 0.f}; bool qda_set = false;
   constexpr bool pd = (VAR >= 1);
   const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
@@ -965,7 +982,6 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
-  load_table(A.table, sTab, threadIdx.x);
   const int env0 = blockIdx.x * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash); }
@@ -979,7 +995,6 @@ __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
-  load_table(A.table, sTab, threadIdx.x);
   const int env0 = blockIdx.x * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash); }
