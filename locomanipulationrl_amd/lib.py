@@ -110,7 +110,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return _SO
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
     # -fno-slp-vectorize: packed fp32 pairs cost more v_mov / AGPR shuffles than they save here (measured: 56.0 -> 58.2 M env-steps/s)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", src, src2, "-o", _SO]
+    # -fno-hip-fp32-correctly-rounded-divide-sqrt: 1/x and sqrt as v_rcp / v_sqrt (1 ulp) instead of the ~10-instruction IEEE sequences
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+           "-fPIC", "-shared", src, src2, "-o", _SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
