@@ -27,7 +27,7 @@ ROLLOUT = 48
 BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (460 read + 1028 written)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v2.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v4.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
 
 
 def cpu_baseline(steps: int = 150, envs: int = 4096):
@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="skip the event-timing and zero-action legs (counter collection runs: every k_step dispatch is then the timed protocol)")
     args = ap.parse_args()
 
     import torch
@@ -114,12 +115,12 @@ def main():
     result = None
     if rank == 0:
         # dominant-kernel time: HIP events around each launch on the launch stream (outside the timed region)
-        n_ev = 200
+        n_ev = 0 if args.timed_only else 200
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
         for i, (a, b) in enumerate(evs):
             a.record(); eng.step(pool[i % 64], None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras); b.record()
         torch.cuda.synchronize(dev)
-        k_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        k_ms = sorted(a.elapsed_time(b) for a, b in evs) or [elapsed / args.steps * 1e3]
         k_avg_ms = sum(k_ms) / len(k_ms)
         achieved = BYTES_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e9
         pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
@@ -128,10 +129,11 @@ def main():
         value = world * N * args.steps / elapsed
         # second protocol of SURVEY 8(d): zero actions (standing robots, only the 300-step timeout resets); rank 0, untimed region
         zact = torch.zeros(N, 12, device=dev)
-        for _ in range(50): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
+        nz = 0 if args.timed_only else 500
+        for _ in range(nz // 10): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
         torch.cuda.synchronize(dev); tz = time.perf_counter()
-        for _ in range(500): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
-        torch.cuda.synchronize(dev); zero_rate = N * 500 / (time.perf_counter() - tz)
+        for _ in range(nz): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
+        torch.cuda.synchronize(dev); zero_rate = N * nz / (time.perf_counter() - tz) if nz else None
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -141,7 +143,7 @@ def main():
                        "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
                        "zero_action_env_steps_per_s_rank0": zero_rate, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_step(+k_finalize)", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
+                         "traffic": traffic, "kernel": "k_step", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
             "valu": {"achieved": flop_env * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flop_env * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64,

@@ -1,9 +1,38 @@
-"""Summarise rocprofv3 --pmc counter_collection.csv files per kernel (per-wave averages for k_step)."""
-import collections, csv, glob, sys
-for d in sys.argv[1:]:
-    for f in sorted(glob.glob(d + "/*/*_counter_collection.csv")):
-        acc = collections.defaultdict(list); waves = 256
+"""Summarise rocprofv3 --pmc counter_collection.csv files of the headline bench per k_step wavefront / launch.
+    python tools/pmc_summary.py <dir> ...          one line per counter file
+    python tools/pmc_summary.py --json <dir>       the profiles/r01_pmc_*.json document (all pmc_* sub-directories of <dir>)"""
+import collections, csv, glob, json, os, sys
+
+
+def collect(d):
+    acc = collections.defaultdict(list); waves = 256
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if r["Kernel_Name"].startswith("k_step"):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"])); waves = int(r["Grid_Size"]) // 64
-        print(d, {k: round(sum(v) / len(v) / waves, 1) for k, v in acc.items()})
+    return {k: sum(v) / len(v) / waves for k, v in acc.items()}, waves
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--json":
+        per_wave, waves = collect(sys.argv[2])
+        pw = {}
+        for k, v in per_wave.items():
+            if k in ("FETCH_SIZE", "WRITE_SIZE"): pw[k + "_KB"] = round(v, 2)
+            elif k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY"): pw[k + "_quad"] = round(v, 1)
+            else: pw[k] = round(v, 1)
+        fetch = per_wave.get("FETCH_SIZE", 0.0) * 1024 * waves; write = per_wave.get("WRITE_SIZE", 0.0) * 1024 * waves
+        flop = (per_wave.get("SQ_INSTS_VALU_ADD_F32", 0) + per_wave.get("SQ_INSTS_VALU_MUL_F32", 0) + per_wave.get("SQ_INSTS_VALU_TRANS_F32", 0)
+                + 2 * per_wave.get("SQ_INSTS_VALU_FMA_F32", 0)) * 64 / 16          # per-lane ops of a 64-lane wavefront holding 16 envs
+        print(json.dumps({
+            "source": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), bench.py --steps 100 --warmup 20, k_step dispatches only, "
+                      f"4096 envs = {waves} wavefronts per launch (tools/profile_round.sh)",
+            "per_wave": pw,
+            "per_launch": {"fetch_bytes": fetch, "write_bytes": write, "hbm_traffic_bytes": fetch + write,
+                           "note": "FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950 (the guide's x2 correction applies to 16 B/lane streams only); "
+                                   "writes include the unclipped obs_buf/states_buf copies the API exposes (+628 B/env) and the per-env reward terms (+44 B/env)"},
+            "flop_per_env_step": flop}, indent=1))
+    else:
+        for d in sys.argv[1:]:
+            pw, waves = collect(d)
+            print(d, {k: round(v, 1) for k, v in pw.items()})
