@@ -213,51 +213,83 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
 #define MLP_OFF_BH (MLP_OFF_WH + 16 * 64)
 #define MLP_PARAMS (MLP_OFF_BH + 16)
 
-// one dense layer: OUT/16 output blocks, IN/4 k-steps; Wp is [mb][step][lane]
-template <int OUT_BLOCKS, int IN_BLOCKS>
-__device__ __forceinline__ void mlp_layer(const float* __restrict__ Wp, const float* __restrict__ bias, const f32x4* in, f32x4* out,
-                                          int lane, int g, bool act) {
-#pragma unroll
-  for (int mb = 0; mb < OUT_BLOCKS; mb++) {
+// ---- counter-based standard normal for the fused action sampling (same generator as lm_engine.hip dr_sample, stream 9)
+__device__ __forceinline__ uint32_t ro_mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
+  uint32_t base = ro_mix32(seed ^ ro_mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ ro_mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ ro_mix32(9U * 0x27D4EB2FU + 0x632BE5ABU));
+  uint32_t r1 = ro_mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = ro_mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+// (episode_count, progress_buf) identifies an env-step: progress restarts at every reset and the episode count moves on
+__device__ __forceinline__ uint32_t ro_key(const int64_t* __restrict__ cnt, int N, int env) {
+  return ((uint32_t)cnt[5 * (size_t)N + env] << 16) + (uint32_t)cnt[4 * (size_t)N + env];
+}
+struct SampleArgs { const float* log_std; const int64_t* cnt; uint32_t seed; float* actions; float* logp; };      // log_std == nullptr: no sampling
+
+// One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU: every layer's output blocks are dealt round-robin to the
+// wavefronts, activations pass from layer to layer through LDS as [feature][sample] (row stride 20 floats: the B-operand reads of the
+// four lane groups then fall on disjoint banks).  Weights are the MFMA A operand, pre-permuted on the host (policies/mlp_model.py).
+#define MLP_LDS_STRIDE 20
+// k-row of the B operand for k-step `st`, lane group g: layer 1 reads the observation in natural order, the later layers in the order
+// the host permutation assumes (16 (st >> 2) + 4 g + (st & 3), i.e. "the previous layer's accumulator tile")
+template <bool NATURAL> __device__ __forceinline__ int mlp_krow(int st, int g) { return NATURAL ? 4 * st + g : 16 * (st >> 2) + 4 * g + (st & 3); }
+
+template <int OUT_BLOCKS, int IN_STEPS, bool NATURAL>
+__device__ __forceinline__ void mlp_layer4(const float* __restrict__ Wp, const float* __restrict__ bias, const float* sIn, float* sOut,
+                                           int wave, int lane, int n, int g, bool act) {
+  for (int mb = wave; mb < OUT_BLOCKS; mb += 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* wp = Wp + (size_t)mb * IN_STEPS * 64 + lane;
+#pragma unroll 16
+    for (int st = 0; st < IN_STEPS; st++)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(size_t)st * 64], sIn[mlp_krow<NATURAL>(st, g) * MLP_LDS_STRIDE + n], acc, 0, 0, 0);
 #pragma unroll
-    for (int st = 0; st < IN_BLOCKS * 4; st++) {
-      float a = Wp[(size_t)(mb * IN_BLOCKS * 4 + st) * 64 + lane];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in[st >> 2][st & 3], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) { float v = acc[i] + bias[16 * mb + 4 * g + i]; acc[i] = act ? elu(v) : v; }
-    out[mb] = acc;
+    for (int i = 0; i < 4; i++) { float v = acc[i] + bias[16 * mb + 4 * g + i]; sOut[(16 * mb + 4 * g + i) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
   }
 }
 
-__global__ void __launch_bounds__(64) k_mlp_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
-                                                    float* __restrict__ mean, float* __restrict__ value) {
-  const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+__global__ void __launch_bounds__(256) k_mlp_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
+                                                     float* __restrict__ mean, float* __restrict__ value, SampleArgs SA) {
+  __shared__ float sX[64 * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2[128 * MLP_LDS_STRIDE], sH3[64 * MLP_LDS_STRIDE], sO[16 * MLP_LDS_STRIDE];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, n = lane & 15, g = lane >> 4;
   const int s0 = blockIdx.x * 16;
-  const int sample = min(s0 + n, B - 1);
-  const float* ob = obs + (size_t)sample * 64;
-  const float clip = W[MLP_OFF_CLIP];
-  // layer-1 input in "k-step" form: x[st] = normalised obs[4 st + g]; stored as 4 pseudo accumulator blocks of 16 features so
-  // that the generic layer can index in[st >> 2][st & 3]
-  f32x4 x[4];
+  {      // normalised, clipped observation tile: thread t -> sample t >> 4, features (t & 15) * 4 .. +3 (one 16-byte load)
+    const int sm = t >> 4, c0 = (t & 15) * 4, sample = min(s0 + sm, B - 1);
+    const float4 o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * 64 + c0);
+    const float clip = W[MLP_OFF_CLIP], o[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
-  for (int st = 0; st < 16; st++) {
-    int c = 4 * st + g;
-    float v = (ob[c] - W[MLP_OFF_MEAN + c]) * W[MLP_OFF_ISTD + c];
-    x[st >> 2][st & 3] = fminf(fmaxf(v, -clip), clip);
+    for (int i = 0; i < 4; i++) {
+      float v = (o[i] - W[MLP_OFF_MEAN + c0 + i]) * W[MLP_OFF_ISTD + c0 + i];
+      sX[(c0 + i) * MLP_LDS_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
+    }
   }
-  f32x4 h1[16], h2[8], h3[4], ho[1];
-  mlp_layer<16, 4>(W + MLP_OFF_W1, W + MLP_OFF_B1, x, h1, lane, g, true);
-  mlp_layer<8, 16>(W + MLP_OFF_W2, W + MLP_OFF_B2, h1, h2, lane, g, true);
-  mlp_layer<4, 8>(W + MLP_OFF_W3, W + MLP_OFF_B3, h2, h3, lane, g, true);
-  mlp_layer<1, 4>(W + MLP_OFF_WH, W + MLP_OFF_BH, h3, ho, lane, g, false);
-  if (s0 + n < B) {
-    if (g < 3) {
+  __syncthreads();
+  mlp_layer4<16, 16, true>(W + MLP_OFF_W1, W + MLP_OFF_B1, sX, sH1, wave, lane, n, g, true);
+  __syncthreads();
+  mlp_layer4<8, 64, false>(W + MLP_OFF_W2, W + MLP_OFF_B2, sH1, sH2, wave, lane, n, g, true);
+  __syncthreads();
+  mlp_layer4<4, 32, false>(W + MLP_OFF_W3, W + MLP_OFF_B3, sH2, sH3, wave, lane, n, g, true);
+  __syncthreads();
+  if (wave != 0) return;
+  mlp_layer4<1, 16, false>(W + MLP_OFF_WH, W + MLP_OFF_BH, sH3, sO, 0, lane, n, g, false);
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+  const int smp = s0 + n;
+  const bool valid = smp < B;
+  float lp = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; i++) mean[(size_t)(s0 + n) * 12 + 4 * g + i] = ho[0][i];
-    } else value[s0 + n] = ho[0][0];
+  for (int i = 0; i < 4; i++) {
+    const int j = 4 * g + i;                      // head output row: 0..11 action means, 12 value
+    const float v = sO[j * MLP_LDS_STRIDE + n];
+    if (valid && j < 12) mean[(size_t)smp * 12 + j] = v;
+    if (valid && j == 12) value[smp] = v;
+    if (SA.log_std && j < 12 && valid) {
+      const float ls = SA.log_std[j], eps = ro_normal(SA.seed, (uint32_t)smp, ro_key(SA.cnt, B, smp), (uint32_t)j);
+      SA.actions[(size_t)smp * 12 + j] = fmaf(expf(ls), eps, v);
+      lp += -0.5f * eps * eps - ls - 0.9189385332046727f;          // log N(a; mean, std) with (a - mean) / std = eps
+    }
   }
+  if (SA.log_std) { lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32); if (valid && g == 0) SA.logp[smp] = lp; }
 }
 
 extern "C" {
@@ -266,7 +298,7 @@ int lm_mlp_param_count(void) { return MLP_PARAMS; }
 
 int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
   if (!obs || !params || !mean || !value || batch <= 0) return -1;
-  hipLaunchKernelGGL(k_mlp_forward, dim3((batch + 15) / 16), dim3(64), 0, (hipStream_t)stream, obs, batch, params, mean, value);
+  SampleArgs SA{}; hipLaunchKernelGGL(k_mlp_forward, dim3((batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, obs, batch, params, mean, value, SA);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -281,28 +313,20 @@ int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean
 
 
 // ------------------------------------------------------------------------------------------------ fused rollout (f-2)
-__device__ __forceinline__ uint32_t ro_mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
-// standard normal from the same counter-based generator as the engine's domain randomisation (lm_engine.hip dr_sample, stream 9)
-__device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
-  uint32_t base = ro_mix32(seed ^ ro_mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ ro_mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ ro_mix32(9U * 0x27D4EB2FU + 0x632BE5ABU));
-  uint32_t r1 = ro_mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = ro_mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
-  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-}
-
 __global__ void __launch_bounds__(256) k_sample_actions(const float* __restrict__ mean, const float* __restrict__ log_std, const int64_t* __restrict__ cnt,
                                                         int N, uint32_t seed, float* __restrict__ actions, float* __restrict__ logp) {
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= N) return;
   // (episode_count, progress_buf) identifies the env-step: progress restarts at every reset and the episode count moves on
-  const uint32_t key = ((uint32_t)cnt[5 * (size_t)N + env] << 16) + (uint32_t)cnt[4 * (size_t)N + env];
-  float lp = 0.f;
+  const uint32_t key = ro_key(cnt, N, env);
+  float part[3] = {0.f, 0.f, 0.f};      // summed in groups of four like the fused epilogue of k_mlp_forward (bit-identical log-probs)
 #pragma unroll
   for (int j = 0; j < 12; j++) {
     const float ls = log_std[j], eps = ro_normal(seed, (uint32_t)env, key, (uint32_t)j);
     actions[(size_t)env * 12 + j] = fmaf(expf(ls), eps, mean[(size_t)env * 12 + j]);
-    lp += -0.5f * eps * eps - ls - 0.9189385332046727f;          // log N(a; mean, std) with (a - mean) / std = eps
+    part[j >> 2] += -0.5f * eps * eps - ls - 0.9189385332046727f;          // log N(a; mean, std) with (a - mean) / std = eps
   }
+  const float lp = (part[0] + part[1]) + (part[2] + 0.f);
   logp[env] = lp;
 }
 
@@ -317,12 +341,18 @@ static int rollout_enqueue(lm_rollout* r, hipStream_t s) {
   const size_t N = (size_t)r->N;
   for (int t = 0; t <= r->T; t++) {
     const float* ob = r->obs + (size_t)t * N * 64;
-    int rc = (r->policy == LM_POLICY_MLP) ? lm_mlp_forward(ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, s)
-                                          : lm_gnn_forward(ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, s);
+    float* act = r->actions + (size_t)(t < r->T ? t : 0) * N * 12;
+    int rc = 0;
+    if (r->policy == LM_POLICY_MLP) {      // sampling fused into the forward's epilogue
+      SampleArgs SA{}; if (t < r->T) { SA.log_std = r->log_std; SA.cnt = r->cnt; SA.seed = r->seed; SA.actions = act; SA.logp = r->logp + (size_t)t * N; }
+      hipLaunchKernelGGL(k_mlp_forward, dim3((r->N + 15) / 16), dim3(256), 0, s, ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, SA);
+    } else {
+      rc = lm_gnn_forward(ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, s);
+      if (!rc && t < r->T)
+        hipLaunchKernelGGL(k_sample_actions, dim3((r->N + 255) / 256), dim3(256), 0, s, r->mean_tmp, r->log_std, r->cnt, r->N, r->seed, act, r->logp + (size_t)t * N);
+    }
     if (rc) return rc;
     if (t == r->T) break;                                        // the last forward only bootstraps the value
-    float* act = r->actions + (size_t)t * N * 12;
-    hipLaunchKernelGGL(k_sample_actions, dim3((r->N + 255) / 256), dim3(256), 0, s, r->mean_tmp, r->log_std, r->cnt, r->N, r->seed, act, r->logp + (size_t)t * N);
     rc = lm_step(r->env, act, nullptr, r->obs + (size_t)(t + 1) * N * 64, nullptr, r->rewards + (size_t)t * N, r->dones + (size_t)t * N,
                  r->extras ? r->extras + (size_t)t * LM_NUM_EXTRAS : nullptr, s);
     if (rc) return rc;
