@@ -49,10 +49,35 @@ __device__ __forceinline__ constexpr int edge_tgt(int e) { return e < 4 ? e + 1 
 // obs column of feature k (0..3) of joint node n (1..12): [0.3 q, 0.3 qd, action, last action] of that joint (:115-126)
 __device__ __forceinline__ constexpr int joint_col(int n, int k) { return 16 + 12 * k + (n <= 4 ? n - 1 : (n <= 8 ? 4 + 2 * (n - 5) : 5 + 2 * (n - 9))); }
 
-__global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
-                                                    float* __restrict__ mean, float* __restrict__ value) {
-  __shared__ float sPQ[GNN_NODES * 64 * GNN_SAMPLES];          // [node][feature 0..63][sample]
-  const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+// ---- counter-based standard normal for the fused action sampling (same generator as lm_engine.hip dr_sample, stream 9)
+__device__ __forceinline__ uint32_t ro_mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
+  uint32_t base = ro_mix32(seed ^ ro_mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ ro_mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ ro_mix32(9U * 0x27D4EB2FU + 0x632BE5ABU));
+  uint32_t r1 = ro_mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = ro_mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+// (episode_count, progress_buf) identifies an env-step: progress restarts at every reset and the episode count moves on
+__device__ __forceinline__ uint32_t ro_key(const int64_t* __restrict__ cnt, int N, int env) {
+  return ((uint32_t)cnt[5 * (size_t)N + env] << 16) + (uint32_t)cnt[4 * (size_t)N + env];
+}
+struct SampleArgs { const float* log_std; const int64_t* cnt; uint32_t seed; float* actions; float* logp; };      // log_std == nullptr: no sampling
+
+// One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU.  Every wavefront OWNS a set of graph nodes: it keeps their features
+// in registers, computes their P / Q projections into LDS, and evaluates the messages along the edges that END in its nodes (max
+// aggregation is order independent, so the result is bit-identical to a single-wavefront evaluation).  Ownership balances the edges,
+// 6 per wavefront: {0,1} (4+2 incoming edges), {2,3,4} (2+2+2), {5,6,7} (2+2+2), {8,...,12} (2+1+1+1+1).
+__device__ __forceinline__ constexpr int gnn_first(int w) { return w == 0 ? 0 : (w == 1 ? 2 : (w == 2 ? 5 : 8)); }
+__device__ __forceinline__ constexpr int gnn_count(int w) { return w == 0 ? 2 : (w == 3 ? 5 : 3); }
+// incoming edges of node t (graph_model_orebot_ov.py:142-159): hub <- its 4 dof1 nodes; dof1 <- hub, dof2; dof2 <- dof1, dof3; dof3 <- dof2
+__device__ __forceinline__ constexpr int gnn_nin(int t) { return t == 0 ? 4 : (t <= 8 ? 2 : 1); }
+__device__ __forceinline__ constexpr int gnn_in(int t, int k) { return t == 0 ? 1 + k : (t <= 4 ? (k == 0 ? 0 : t + 4) : (t <= 8 ? (k == 0 ? t - 4 : t + 4) : t - 4)); }
+
+template <int WAVE>
+__device__ __forceinline__ void gnn_body(const float* __restrict__ obs, int B, const float* __restrict__ W, float* __restrict__ mean,
+                                         float* __restrict__ value, const SampleArgs& SA, float* sPQ, float* sHm, float* sLp, int lane) {
+  constexpr int N0 = gnn_first(WAVE), NC = gnn_count(WAVE);
+  const int n = lane & 15, g = lane >> 4;
   const int s0 = blockIdx.x * GNN_SAMPLES;
   const int sample = min(s0 + n, B - 1);
   const float* obr = obs + (size_t)sample * 64;
@@ -60,35 +85,31 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
   // normalised observation column c of this lane's sample
   auto ob = [&](int c) { float v = (obr[c] - W[OFF_OBS_MEAN + c]) * W[OFF_OBS_ISTD + c]; return fminf(fmaxf(v, -oclip), oclip); };
 
-  f32x4 h[GNN_NODES][2];            // node features, C layout: h[node][mb][i] = feature 16 mb + 4 g + i of sample n
+  f32x4 h[NC][2];            // features of the owned nodes, C layout: h[j][mb][i] = feature 16 mb + 4 g + i of sample n
   // ---- input layers (:97-104)
-  {
-    // node 0: Linear(16,32) on obs[0:16]
 #pragma unroll
-    for (int mb = 0; mb < 2; mb++) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        float a = W[OFF_IN1_W + (16 * mb + n) * 16 + 4 * s + g];
-        float b = ob(4 * s + g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) acc[i] += W[OFF_IN1_B + 16 * mb + 4 * g + i];
-      h[0][mb] = acc;
-    }
-    // joint nodes: shared Linear(4,32)
-    float a2[2] = {W[OFF_IN2_W + (n) * 4 + g], W[OFF_IN2_W + (16 + n) * 4 + g]};
-#pragma unroll
-    for (int nd = 1; nd < GNN_NODES; nd++) {
-      float b = ob(joint_col(nd, 0) + 12 * g);        // feature g of the joint: columns 16+j, 28+j, 40+j, 52+j
+  for (int j = 0; j < NC; j++) {
+    const int nd = N0 + j;
+    if (nd == 0) {      // hub node: Linear(16,32) on obs[0:16]
 #pragma unroll
       for (int mb = 0; mb < 2; mb++) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb], b, acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[OFF_IN1_W + (16 * mb + n) * 16 + 4 * s + g], ob(4 * s + g), acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] += W[OFF_IN1_B + 16 * mb + 4 * g + i];
+        h[j][mb] = acc;
+      }
+    } else {            // joint nodes: shared Linear(4,32) on [0.3 q, 0.3 qd, action, last action] of the joint
+      const float bcol = ob(joint_col(nd, 0) + 12 * g);
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[OFF_IN2_W + (16 * mb + n) * 4 + g], bcol, acc, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] += W[OFF_IN2_B + 16 * mb + 4 * g + i];
-        h[nd][mb] = acc;
+        h[j][mb] = acc;
       }
     }
   }
@@ -96,100 +117,141 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
   for (int layer = 0; layer < 3; layer++) {
     const float* L = W + OFF_LAYER0 + layer * LAYER_STRIDE;
     const float* W1 = L; const float* b1 = L + 2048; const float* W2 = L + 2080; const float* b2 = L + 3104;
-    // stage 1: P = W1[:, 0:32] h + b1, Q = W1[:, 32:64] h  for every node -> LDS.
-    // output feature block ob4 (0,1 = P rows 0..31; 2,3 = Q rows 0..31); k-step (mb', i) reads h[node][mb'][i] = feature 16 mb' + 4 g + i
-    float wa[4][8];
-#pragma unroll
-    for (int ob4 = 0; ob4 < 4; ob4++)
-#pragma unroll
-      for (int st = 0; st < 8; st++) {
-        int row = 16 * (ob4 & 1) + n, col = 32 * (ob4 >> 1) + 16 * (st >> 2) + 4 * g + (st & 3);
-        wa[ob4][st] = W1[row * 64 + col];
-      }
-    float bias1[2][4];
-#pragma unroll
-    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) bias1[mb][i] = b1[16 * mb + 4 * g + i];
-#pragma unroll
-    for (int nd = 0; nd < GNN_NODES; nd++) {
-      f32x4 acc[4];
-#pragma unroll
-      for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int st = 0; st < 8; st++) {
-        float b = h[nd][st >> 2][st & 3];
-#pragma unroll
-        for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ob4][st], b, acc[ob4], 0, 0, 0);
-      }
+    // stage 1: P = W1[:, 0:32] h + b1, Q = W1[:, 32:64] h of the owned nodes -> LDS.
+    // output feature block ob4 (0,1 = P rows 0..31; 2,3 = Q rows 0..31); k-step (mb', i) reads h[.][mb'][i] = feature 16 mb' + 4 g + i
+    {
+      float wa[4][8];
 #pragma unroll
       for (int ob4 = 0; ob4 < 4; ob4++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          float v = acc[ob4][i] + ((ob4 < 2) ? bias1[ob4][i] : 0.f);
-          sPQ[(nd * 64 + 16 * ob4 + 4 * g + i) * GNN_SAMPLES + n] = v;
+        for (int st = 0; st < 8; st++) wa[ob4][st] = W1[(16 * (ob4 & 1) + n) * 64 + 32 * (ob4 >> 1) + 16 * (st >> 2) + 4 * g + (st & 3)];
+      float bias1[2][4];
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) bias1[mb][i] = b1[16 * mb + 4 * g + i];
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+          const float bb = h[j][st >> 2][st & 3];
+#pragma unroll
+          for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ob4][st], bb, acc[ob4], 0, 0, 0);
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    // stage 2: messages along the 24 edges, max-aggregated on the target node
-    float wb[2][8];
 #pragma unroll
-    for (int mb = 0; mb < 2; mb++)
+        for (int ob4 = 0; ob4 < 4; ob4++)
 #pragma unroll
-      for (int st = 0; st < 8; st++) wb[mb][st] = W2[(16 * mb + n) * 32 + 4 * st + g];
-    float bias2[2][4];
-#pragma unroll
-    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
-#pragma unroll
-    for (int nd = 0; nd < GNN_NODES; nd++)
-#pragma unroll
-      for (int mb = 0; mb < 2; mb++) h[nd][mb] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-#pragma unroll
-    for (int e = 0; e < GNN_EDGES; e++) {
-      const int src = edge_src(e), tgt = edge_tgt(e);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int st = 0; st < 8; st++) {
-        int k = 4 * st + g;
-        float z = elu(sPQ[(tgt * 64 + k) * GNN_SAMPLES + n] + sPQ[(src * 64 + 32 + k) * GNN_SAMPLES + n]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], z, acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        h[tgt][0][i] = fmaxf(h[tgt][0][i], elu(acc0[i] + bias2[0][i]));
-        h[tgt][1][i] = fmaxf(h[tgt][1][i], elu(acc1[i] + bias2[1][i]));
+          for (int i = 0; i < 4; i++)
+            sPQ[((N0 + j) * 64 + 16 * ob4 + 4 * g + i) * GNN_SAMPLES + n] = acc[ob4][i] + ((ob4 < 2) ? bias1[ob4][i] : 0.f);
       }
     }
-    __builtin_amdgcn_wave_barrier();       // all lanes done reading sPQ before the next layer overwrites it
+    __syncthreads();
+    // stage 2: messages along the edges that end in the owned nodes, max-aggregated
+    {
+      float wb[2][8];
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+        for (int st = 0; st < 8; st++) wb[mb][st] = W2[(16 * mb + n) * 32 + 4 * st + g];
+      float bias2[2][4];
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        const int tgt = N0 + j;
+        h[j][0] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; h[j][1] = h[j][0];
+#pragma unroll
+        for (int k = 0; k < gnn_nin(tgt); k++) {
+          const int src = gnn_in(tgt, k);
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < 8; st++) {
+            const int kk = 4 * st + g;
+            const float z = elu(sPQ[(tgt * 64 + kk) * GNN_SAMPLES + n] + sPQ[(src * 64 + 32 + kk) * GNN_SAMPLES + n]);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], z, acc1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            h[j][0][i] = fmaxf(h[j][0][i], elu(acc0[i] + bias2[0][i]));
+            h[j][1][i] = fmaxf(h[j][1][i], elu(acc1[i] + bias2[1][i]));
+          }
+        }
+      }
+    }
+    __syncthreads();       // every wavefront is done reading sPQ before the next layer overwrites it
   }
   // ---- heads (:215-241): action mean of joint node j = Linear(32,1)(h[1+j]); value = Linear(32,1)(max over nodes)
-  float wact[2][4], wval[2][4];
+  float wact[2][4];
 #pragma unroll
   for (int mb = 0; mb < 2; mb++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) { wact[mb][i] = W[OFF_ACT_W + 16 * mb + 4 * g + i]; wval[mb][i] = W[OFF_VAL_W + 16 * mb + 4 * g + i]; }
+    for (int i = 0; i < 4; i++) wact[mb][i] = W[OFF_ACT_W + 16 * mb + 4 * g + i];
   const bool write = (g == 0) && (s0 + n < B);
   f32x4 hm0 = h[0][0], hm1 = h[0][1];
 #pragma unroll
-  for (int nd = 1; nd < GNN_NODES; nd++) {
+  for (int j = 0; j < NC; j++) {
+    const int nd = N0 + j;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { hm0[i] = fmaxf(hm0[i], h[j][0][i]); hm1[i] = fmaxf(hm1[i], h[j][1][i]); }
+    if (nd == 0) continue;
     float p = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      p = fmaf(wact[0][i], h[nd][0][i], p); p = fmaf(wact[1][i], h[nd][1][i], p);
-      hm0[i] = fmaxf(hm0[i], h[nd][0][i]); hm1[i] = fmaxf(hm1[i], h[nd][1][i]);
-    }
+    for (int i = 0; i < 4; i++) { p = fmaf(wact[0][i], h[j][0][i], p); p = fmaf(wact[1][i], h[j][1][i], p); }
     p += __shfl_xor(p, 16); p += __shfl_xor(p, 32);
-    if (write) mean[(size_t)(s0 + n) * 12 + (nd - 1)] = p + W[OFF_ACT_B];
+    const float m = p + W[OFF_ACT_B];
+    if (write) {
+      mean[(size_t)(s0 + n) * 12 + (nd - 1)] = m;
+      if (SA.log_std) {
+        const int a = nd - 1, smp = s0 + n;
+        const float ls = SA.log_std[a], eps = ro_normal(SA.seed, (uint32_t)smp, ro_key(SA.cnt, B, smp), (uint32_t)a);
+        SA.actions[(size_t)smp * 12 + a] = fmaf(expf(ls), eps, m);
+        sLp[a * GNN_SAMPLES + n] = -0.5f * eps * eps - ls - 0.9189385332046727f;
+      }
+    }
   }
+  // value head: max over all nodes = max over the four wavefronts' partial maxima
+#pragma unroll
+  for (int i = 0; i < 4; i++) { sHm[((WAVE * 32) + 4 * g + i) * GNN_SAMPLES + n] = hm0[i]; sHm[((WAVE * 32) + 16 + 4 * g + i) * GNN_SAMPLES + n] = hm1[i]; }
+  __syncthreads();
+  if (WAVE != 0) return;
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { v = fmaf(wval[0][i], hm0[i], v); v = fmaf(wval[1][i], hm1[i], v); }
+  for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int f = 16 * mb + 4 * g + i;
+      const float m4 = fmaxf(fmaxf(sHm[(0 * 32 + f) * GNN_SAMPLES + n], sHm[(1 * 32 + f) * GNN_SAMPLES + n]),
+                             fmaxf(sHm[(2 * 32 + f) * GNN_SAMPLES + n], sHm[(3 * 32 + f) * GNN_SAMPLES + n]));
+      v = fmaf(W[OFF_VAL_W + f], m4, v);
+    }
   v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-  if (write) value[s0 + n] = v + W[OFF_VAL_B];
+  if (write) {
+    value[s0 + n] = v + W[OFF_VAL_B];
+    if (SA.log_std) {      // summed in groups of four like k_sample_actions (bit-identical log-probs)
+      float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 12; a++) part[a >> 2] += sLp[a * GNN_SAMPLES + n];
+      SA.logp[s0 + n] = (part[0] + part[1]) + (part[2] + 0.f);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gnn_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
+                                                     float* __restrict__ mean, float* __restrict__ value, SampleArgs SA) {
+  __shared__ float sPQ[GNN_NODES * 64 * GNN_SAMPLES];          // [node][feature 0..63][sample]
+  __shared__ float sHm[4 * 32 * GNN_SAMPLES];                  // per-wavefront node maxima for the value head
+  __shared__ float sLp[12 * GNN_SAMPLES];                      // per-action log-prob terms
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave == 0) gnn_body<0>(obs, B, W, mean, value, SA, sPQ, sHm, sLp, lane);
+  else if (wave == 1) gnn_body<1>(obs, B, W, mean, value, SA, sPQ, sHm, sLp, lane);
+  else if (wave == 2) gnn_body<2>(obs, B, W, mean, value, SA, sPQ, sHm, sLp, lane);
+  else gnn_body<3>(obs, B, W, mean, value, SA, sPQ, sHm, sLp, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,20 +274,6 @@ __global__ void __launch_bounds__(64) k_gnn_forward(const float* __restrict__ ob
 #define MLP_OFF_WH (MLP_OFF_B3 + 64)
 #define MLP_OFF_BH (MLP_OFF_WH + 16 * 64)
 #define MLP_PARAMS (MLP_OFF_BH + 16)
-
-// ---- counter-based standard normal for the fused action sampling (same generator as lm_engine.hip dr_sample, stream 9)
-__device__ __forceinline__ uint32_t ro_mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
-__device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
-  uint32_t base = ro_mix32(seed ^ ro_mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ ro_mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ ro_mix32(9U * 0x27D4EB2FU + 0x632BE5ABU));
-  uint32_t r1 = ro_mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = ro_mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
-  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-}
-// (episode_count, progress_buf) identifies an env-step: progress restarts at every reset and the episode count moves on
-__device__ __forceinline__ uint32_t ro_key(const int64_t* __restrict__ cnt, int N, int env) {
-  return ((uint32_t)cnt[5 * (size_t)N + env] << 16) + (uint32_t)cnt[4 * (size_t)N + env];
-}
-struct SampleArgs { const float* log_std; const int64_t* cnt; uint32_t seed; float* actions; float* logp; };      // log_std == nullptr: no sampling
 
 // One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU: every layer's output blocks are dealt round-robin to the
 // wavefronts, activations pass from layer to layer through LDS as [feature][sample] (row stride 20 floats: the B-operand reads of the
@@ -307,7 +355,7 @@ int lm_gnn_param_count(void) { return GNN_PARAMS; }
 int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
   if (!obs || !params || !mean || !value || batch <= 0) return -1;
   int blocks = (batch + GNN_SAMPLES - 1) / GNN_SAMPLES;
-  hipLaunchKernelGGL(k_gnn_forward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, obs, batch, params, mean, value);
+  SampleArgs SA{}; hipLaunchKernelGGL(k_gnn_forward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, obs, batch, params, mean, value, SA);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -343,14 +391,12 @@ static int rollout_enqueue(lm_rollout* r, hipStream_t s) {
     const float* ob = r->obs + (size_t)t * N * 64;
     float* act = r->actions + (size_t)(t < r->T ? t : 0) * N * 12;
     int rc = 0;
-    if (r->policy == LM_POLICY_MLP) {      // sampling fused into the forward's epilogue
-      SampleArgs SA{}; if (t < r->T) { SA.log_std = r->log_std; SA.cnt = r->cnt; SA.seed = r->seed; SA.actions = act; SA.logp = r->logp + (size_t)t * N; }
+    SampleArgs SA{};       // sampling fused into the forward's epilogue
+    if (t < r->T) { SA.log_std = r->log_std; SA.cnt = r->cnt; SA.seed = r->seed; SA.actions = act; SA.logp = r->logp + (size_t)t * N; }
+    if (r->policy == LM_POLICY_MLP)
       hipLaunchKernelGGL(k_mlp_forward, dim3((r->N + 15) / 16), dim3(256), 0, s, ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, SA);
-    } else {
-      rc = lm_gnn_forward(ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, s);
-      if (!rc && t < r->T)
-        hipLaunchKernelGGL(k_sample_actions, dim3((r->N + 255) / 256), dim3(256), 0, s, r->mean_tmp, r->log_std, r->cnt, r->N, r->seed, act, r->logp + (size_t)t * N);
-    }
+    else
+      hipLaunchKernelGGL(k_gnn_forward, dim3((r->N + GNN_SAMPLES - 1) / GNN_SAMPLES), dim3(256), 0, s, ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, SA);
     if (rc) return rc;
     if (t == r->T) break;                                        // the last forward only bootstraps the value
     rc = lm_step(r->env, act, nullptr, r->obs + (size_t)(t + 1) * N * 64, nullptr, r->rewards + (size_t)t * N, r->dones + (size_t)t * N,
