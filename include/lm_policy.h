@@ -31,6 +31,10 @@ int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean
  * lm_mlp_param_count() is its length.  Outputs as lm_gnn_forward (mean in the env's action order). */
 int lm_mlp_param_count(void);
 int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream);
+/* The same network on the 88-wide observation of the custom-controller tasks (…custom_controller.py:432-455) or the 64-wide one:
+ * num_obs in {64, 88}; the packed block is  mean num_obs | 1/std num_obs | clip (+3 pad) | W1p 256 x num_obs | ... as above. */
+int lm_mlp_param_count_obs(int num_obs);
+int lm_mlp_forward_obs(const float* obs, int batch, int num_obs, const float* params, float* mean, float* value, void* stream);
 
 /* ---- fused rollout: policy forward -> gaussian action sampling -> lm_step, T times, as ONE hipGraph launch.
  * Replaces the per-step Python of the reference's trainer loop (skrl SequentialTrainer / scripts/random_policy.py:52-61:
@@ -46,8 +50,9 @@ enum { LM_POLICY_MLP = 0, LM_POLICY_GNN = 1 };
 int lm_sample_actions(const float* mean, const float* log_std, const int64_t* cnt, int n_envs, uint32_t seed,
                       float* actions, float* logp, void* stream);
 
-/* Plan a rollout of T steps on `env` (64-wide observations).  All buffers are device memory owned by the caller and must stay valid:
- *   obs [T+1][N][64]   obs[0] = the current (clipped) observations on entry; obs[t+1] = those returned by step t
+/* Plan a rollout of T steps on `env`.  All buffers are device memory owned by the caller and must stay valid:
+ *   obs [T+1][N][lm_num_obs(env)]   obs[0] = the current (clipped) observations on entry; obs[t+1] = those returned by step t
+ *                      (88-wide observations: MLP policy only)
  *   actions [T][N][12], logp [T][N], values [T+1][N] (value head output; values[T] bootstraps), rewards [T][N], dones int64 [T][N],
  *   extras [T][LM_NUM_EXTRAS] (may be NULL)
  *   policy_params / log_std: device blocks read at run time (update them in place between runs) */

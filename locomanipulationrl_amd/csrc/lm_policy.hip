@@ -262,18 +262,19 @@ __global__ void __launch_bounds__(256) k_gnn_forward(const float* __restrict__ o
 // in accumulator layout from layer to layer.
 //   packed block: obs_mean 64 | obs_inv_std 64 | clip 1 (+3 pad) | W1p 256x64 | b1 256 | W2p 128x256 | b2 128 | W3p 64x128 | b3 64 |
 //                 Whp 16x64 (rows 0..11 mean, 12 value, 13..15 zero) | bh 16
-#define MLP_OFF_MEAN 0
-#define MLP_OFF_ISTD 64
-#define MLP_OFF_CLIP 128
-#define MLP_OFF_W1 132
-#define MLP_OFF_B1 (MLP_OFF_W1 + 256 * 64)
-#define MLP_OFF_W2 (MLP_OFF_B1 + 256)
-#define MLP_OFF_B2 (MLP_OFF_W2 + 128 * 256)
-#define MLP_OFF_W3 (MLP_OFF_B2 + 128)
-#define MLP_OFF_B3 (MLP_OFF_W3 + 64 * 128)
-#define MLP_OFF_WH (MLP_OFF_B3 + 64)
-#define MLP_OFF_BH (MLP_OFF_WH + 16 * 64)
-#define MLP_PARAMS (MLP_OFF_BH + 16)
+// offsets as functions of the observation width NOBS (64: velocity-drive / position-control tasks, 88: custom-controller tasks)
+__host__ __device__ constexpr int mlp_off_mean(int) { return 0; }
+__host__ __device__ constexpr int mlp_off_istd(int nobs) { return nobs; }
+__host__ __device__ constexpr int mlp_off_clip(int nobs) { return 2 * nobs; }
+__host__ __device__ constexpr int mlp_off_w1(int nobs) { return 2 * nobs + 4; }
+__host__ __device__ constexpr int mlp_off_b1(int nobs) { return mlp_off_w1(nobs) + 256 * nobs; }
+__host__ __device__ constexpr int mlp_off_w2(int nobs) { return mlp_off_b1(nobs) + 256; }
+__host__ __device__ constexpr int mlp_off_b2(int nobs) { return mlp_off_w2(nobs) + 128 * 256; }
+__host__ __device__ constexpr int mlp_off_w3(int nobs) { return mlp_off_b2(nobs) + 128; }
+__host__ __device__ constexpr int mlp_off_b3(int nobs) { return mlp_off_w3(nobs) + 64 * 128; }
+__host__ __device__ constexpr int mlp_off_wh(int nobs) { return mlp_off_b3(nobs) + 64; }
+__host__ __device__ constexpr int mlp_off_bh(int nobs) { return mlp_off_wh(nobs) + 16 * 64; }
+__host__ __device__ constexpr int mlp_params(int nobs) { return mlp_off_bh(nobs) + 16; }
 
 // One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU: every layer's output blocks are dealt round-robin to the
 // wavefronts, activations pass from layer to layer through LDS as [feature][sample] (row stride 20 floats: the B-operand reads of the
@@ -289,7 +290,8 @@ __device__ __forceinline__ void mlp_layer4(const float* __restrict__ Wp, const f
   for (int mb = wave; mb < OUT_BLOCKS; mb += 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* wp = Wp + (size_t)mb * IN_STEPS * 64 + lane;
-#pragma unroll 16
+    constexpr int UNR = (IN_STEPS % 16 == 0) ? 16 : 11;
+#pragma unroll UNR
     for (int st = 0; st < IN_STEPS; st++)
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(size_t)st * 64], sIn[mlp_krow<NATURAL>(st, g) * MLP_LDS_STRIDE + n], acc, 0, 0, 0);
 #pragma unroll
@@ -297,30 +299,32 @@ __device__ __forceinline__ void mlp_layer4(const float* __restrict__ Wp, const f
   }
 }
 
+template <int NOBS>
 __global__ void __launch_bounds__(256) k_mlp_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
                                                      float* __restrict__ mean, float* __restrict__ value, SampleArgs SA) {
-  __shared__ float sX[64 * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2[128 * MLP_LDS_STRIDE], sH3[64 * MLP_LDS_STRIDE], sO[16 * MLP_LDS_STRIDE];
+  __shared__ float sX[NOBS * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2[128 * MLP_LDS_STRIDE], sH3[64 * MLP_LDS_STRIDE], sO[16 * MLP_LDS_STRIDE];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, n = lane & 15, g = lane >> 4;
   const int s0 = blockIdx.x * 16;
-  {      // normalised, clipped observation tile: thread t -> sample t >> 4, features (t & 15) * 4 .. +3 (one 16-byte load)
-    const int sm = t >> 4, c0 = (t & 15) * 4, sample = min(s0 + sm, B - 1);
-    const float4 o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * 64 + c0);
-    const float clip = W[MLP_OFF_CLIP], o[4] = {o4.x, o4.y, o4.z, o4.w};
+  // normalised, clipped observation tile: one 16-byte load per (sample, 4 features)
+  for (int idx = t; idx < 16 * (NOBS / 4); idx += 256) {
+    const int sm = idx / (NOBS / 4), c0 = (idx - sm * (NOBS / 4)) * 4, sample = min(s0 + sm, B - 1);
+    const float4 o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * NOBS + c0);
+    const float clip = W[mlp_off_clip(NOBS)], o[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      float v = (o[i] - W[MLP_OFF_MEAN + c0 + i]) * W[MLP_OFF_ISTD + c0 + i];
+      float v = (o[i] - W[mlp_off_mean(NOBS) + c0 + i]) * W[mlp_off_istd(NOBS) + c0 + i];
       sX[(c0 + i) * MLP_LDS_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
     }
   }
   __syncthreads();
-  mlp_layer4<16, 16, true>(W + MLP_OFF_W1, W + MLP_OFF_B1, sX, sH1, wave, lane, n, g, true);
+  mlp_layer4<16, NOBS / 4, true>(W + mlp_off_w1(NOBS), W + mlp_off_b1(NOBS), sX, sH1, wave, lane, n, g, true);
   __syncthreads();
-  mlp_layer4<8, 64, false>(W + MLP_OFF_W2, W + MLP_OFF_B2, sH1, sH2, wave, lane, n, g, true);
+  mlp_layer4<8, 64, false>(W + mlp_off_w2(NOBS), W + mlp_off_b2(NOBS), sH1, sH2, wave, lane, n, g, true);
   __syncthreads();
-  mlp_layer4<4, 32, false>(W + MLP_OFF_W3, W + MLP_OFF_B3, sH2, sH3, wave, lane, n, g, true);
+  mlp_layer4<4, 32, false>(W + mlp_off_w3(NOBS), W + mlp_off_b3(NOBS), sH2, sH3, wave, lane, n, g, true);
   __syncthreads();
   if (wave != 0) return;
-  mlp_layer4<1, 16, false>(W + MLP_OFF_WH, W + MLP_OFF_BH, sH3, sO, 0, lane, n, g, false);
+  mlp_layer4<1, 16, false>(W + mlp_off_wh(NOBS), W + mlp_off_bh(NOBS), sH3, sO, 0, lane, n, g, false);
   __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
   const int smp = s0 + n;
   const bool valid = smp < B;
@@ -342,12 +346,22 @@ __global__ void __launch_bounds__(256) k_mlp_forward(const float* __restrict__ o
 
 extern "C" {
 
-int lm_mlp_param_count(void) { return MLP_PARAMS; }
+static int mlp_launch(const float* obs, int batch, int num_obs, const float* params, float* mean, float* value, const SampleArgs& SA, hipStream_t s) {
+  if (num_obs == 64) hipLaunchKernelGGL(k_mlp_forward<64>, dim3((batch + 15) / 16), dim3(256), 0, s, obs, batch, params, mean, value, SA);
+  else if (num_obs == 88) hipLaunchKernelGGL(k_mlp_forward<88>, dim3((batch + 15) / 16), dim3(256), 0, s, obs, batch, params, mean, value, SA);
+  else return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int lm_mlp_param_count(void) { return mlp_params(64); }
+int lm_mlp_param_count_obs(int num_obs) { return (num_obs == 64 || num_obs == 88) ? mlp_params(num_obs) : -1; }
+int lm_mlp_forward_obs(const float* obs, int batch, int num_obs, const float* params, float* mean, float* value, void* stream) {
+  if (!obs || !params || !mean || !value || batch <= 0) return -1;
+  SampleArgs SA{}; return mlp_launch(obs, batch, num_obs, params, mean, value, SA, (hipStream_t)stream);
+}
 
 int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
-  if (!obs || !params || !mean || !value || batch <= 0) return -1;
-  SampleArgs SA{}; hipLaunchKernelGGL(k_mlp_forward, dim3((batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, obs, batch, params, mean, value, SA);
-  return hipGetLastError() == hipSuccess ? 0 : -2;
+  return lm_mlp_forward_obs(obs, batch, 64, params, mean, value, stream);
 }
 
 int lm_gnn_param_count(void) { return GNN_PARAMS; }
@@ -379,7 +393,7 @@ __global__ void __launch_bounds__(256) k_sample_actions(const float* __restrict_
 }
 
 struct lm_rollout {
-  lm_engine* env; int policy, T, N; uint32_t seed;
+  lm_engine* env; int policy, T, N, nobs; uint32_t seed;
   const float *params, *log_std; float *obs, *actions, *logp, *values, *rewards, *extras; int64_t* dones;
   float* mean_tmp; const int64_t* cnt;
   hipGraphExec_t exec; hipStream_t exec_stream;
@@ -388,18 +402,17 @@ struct lm_rollout {
 static int rollout_enqueue(lm_rollout* r, hipStream_t s) {
   const size_t N = (size_t)r->N;
   for (int t = 0; t <= r->T; t++) {
-    const float* ob = r->obs + (size_t)t * N * 64;
+    const float* ob = r->obs + (size_t)t * N * r->nobs;
     float* act = r->actions + (size_t)(t < r->T ? t : 0) * N * 12;
     int rc = 0;
     SampleArgs SA{};       // sampling fused into the forward's epilogue
     if (t < r->T) { SA.log_std = r->log_std; SA.cnt = r->cnt; SA.seed = r->seed; SA.actions = act; SA.logp = r->logp + (size_t)t * N; }
-    if (r->policy == LM_POLICY_MLP)
-      hipLaunchKernelGGL(k_mlp_forward, dim3((r->N + 15) / 16), dim3(256), 0, s, ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, SA);
+    if (r->policy == LM_POLICY_MLP) { int rcm = mlp_launch(ob, r->N, r->nobs, r->params, r->mean_tmp, r->values + (size_t)t * N, SA, s); if (rcm) return rcm; }
     else
       hipLaunchKernelGGL(k_gnn_forward, dim3((r->N + GNN_SAMPLES - 1) / GNN_SAMPLES), dim3(256), 0, s, ob, r->N, r->params, r->mean_tmp, r->values + (size_t)t * N, SA);
     if (rc) return rc;
     if (t == r->T) break;                                        // the last forward only bootstraps the value
-    rc = lm_step(r->env, act, nullptr, r->obs + (size_t)(t + 1) * N * 64, nullptr, r->rewards + (size_t)t * N, r->dones + (size_t)t * N,
+    rc = lm_step(r->env, act, nullptr, r->obs + (size_t)(t + 1) * N * r->nobs, nullptr, r->rewards + (size_t)t * N, r->dones + (size_t)t * N,
                  r->extras ? r->extras + (size_t)t * LM_NUM_EXTRAS : nullptr, s);
     if (rc) return rc;
   }
@@ -416,10 +429,11 @@ int lm_rollout_create(lm_rollout** out, lm_engine* env, int policy, const float*
                       float* obs, float* actions, float* logp, float* values, float* rewards, int64_t* dones, float* extras) {
   if (!out || !env || !policy_params || !log_std || !obs || !actions || !logp || !values || !rewards || !dones || T <= 0) return -1;
   if (policy != LM_POLICY_MLP && policy != LM_POLICY_GNN) return -1;
-  if (lm_num_obs(env) != 64) return -1;                           // both forward kernels take the 64-wide observation
+  const int nobs = lm_num_obs(env);
+  if (nobs != 64 && !(nobs == 88 && policy == LM_POLICY_MLP)) return -1;      // the GNN reads the 64-wide layout; the MLP also the 88-wide one
   lm_rollout* r = new (std::nothrow) lm_rollout();
   if (!r) return -3;
-  r->env = env; r->policy = policy; r->T = T; r->N = lm_num_envs(env); r->seed = noise_seed;
+  r->env = env; r->policy = policy; r->T = T; r->N = lm_num_envs(env); r->nobs = nobs; r->seed = noise_seed;
   r->params = policy_params; r->log_std = log_std; r->obs = obs; r->actions = actions; r->logp = logp; r->values = values;
   r->rewards = rewards; r->dones = dones; r->extras = extras; r->exec = nullptr; r->exec_stream = nullptr;
   r->cnt = (const int64_t*)lm_ptr(env, LM_PTR_CNT);

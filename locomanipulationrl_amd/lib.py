@@ -22,7 +22,7 @@ PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_ST
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
            "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_num_obs", "lm_set_seed", "lm_last_error", "lm_version",
-           "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward",
+           "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward", "lm_mlp_param_count_obs", "lm_mlp_forward_obs",
            "lm_sample_actions", "lm_rollout_create", "lm_rollout_run", "lm_rollout_destroy"]
 
 # rows of the SoA float state
@@ -148,6 +148,8 @@ def load_library() -> C.CDLL:
     lib.lm_set_seed.argtypes = [vp, C.c_uint32]
     lib.lm_gnn_forward.argtypes = [fp, ip, fp, fp, fp, vp]
     lib.lm_mlp_forward.argtypes = [fp, ip, fp, fp, fp, vp]
+    lib.lm_mlp_param_count_obs.argtypes = [ip]
+    lib.lm_mlp_forward_obs.argtypes = [fp, ip, ip, fp, fp, fp, vp]
     lib.lm_sample_actions.argtypes = [fp, fp, vp, ip, C.c_uint32, fp, fp, vp]
     lib.lm_rollout_create.argtypes = [C.POINTER(vp), vp, ip, fp, fp, ip, C.c_uint32, fp, fp, fp, fp, fp, vp, fp]
     lib.lm_rollout_run.argtypes = [vp, ip, vp]
@@ -329,16 +331,16 @@ class Rollout:
     def __init__(self, engine: Engine, policy: int, packed_params, log_std, T: int, noise_seed: int = 0):
         torch = engine.torch
         self.engine, self.T, self.N = engine, int(T), engine.num_envs
-        assert engine.num_obs == 64, "the forward kernels take the 64-wide observation"
+        assert engine.num_obs == 64 or (engine.num_obs == 88 and policy == POLICY_MLP), "the GNN reads the 64-wide layout; the MLP 64 or 88"
         dev = engine.device
         assert packed_params.is_cuda and packed_params.dtype == torch.float32 and packed_params.is_contiguous()
         assert log_std.is_cuda and log_std.dtype == torch.float32 and log_std.numel() == 12 and log_std.is_contiguous()
-        n_expected = engine.lib.lm_mlp_param_count() if policy == POLICY_MLP else engine.lib.lm_gnn_param_count()
+        n_expected = engine.lib.lm_mlp_param_count_obs(engine.num_obs) if policy == POLICY_MLP else engine.lib.lm_gnn_param_count()
         assert packed_params.numel() == n_expected, (packed_params.numel(), n_expected)
         self.params, self.log_std = packed_params, log_std
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         T, N = self.T, self.N
-        self.obs, self.actions, self.logp, self.values = z(T + 1, N, 64), z(T, N, 12), z(T, N), z(T + 1, N)
+        self.obs, self.actions, self.logp, self.values = z(T + 1, N, engine.num_obs), z(T, N, 12), z(T, N), z(T + 1, N)
         self.rewards, self.dones, self.extras = z(T, N), z(T, N, dt=torch.int64), z(T, NUM_EXTRAS)
         self._h = C.c_void_p()
         p = Engine._p

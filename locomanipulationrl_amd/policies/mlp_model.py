@@ -47,9 +47,11 @@ def _permute(W: torch.Tensor, natural_k: bool) -> torch.Tensor:
 
 def pack_mlp_params(m: SharedMLP, obs_mean=None, obs_var=None, eps=1e-8, clip=5.0) -> torch.Tensor:
     dev = m.log_std_parameter.device
-    mean = torch.zeros(64, device=dev) if obs_mean is None else obs_mean.detach().float().to(dev)
+    nobs = m.net[0].in_features
+    assert nobs in (64, 88), "the MFMA forward is built for the 64- and 88-wide observations"
+    mean = torch.zeros(nobs, device=dev) if obs_mean is None else obs_mean.detach().float().to(dev)
     # RunningStandardScaler: (x - mean) / (sqrt(var) + eps), then clamp(+-clip); identity statistics when absent
-    istd = torch.ones(64, device=dev) if obs_var is None else 1.0 / (obs_var.detach().float().to(dev).sqrt() + eps)
+    istd = torch.ones(nobs, device=dev) if obs_var is None else 1.0 / (obs_var.detach().float().to(dev).sqrt() + eps)
     clipv = torch.tensor([clip if obs_var is not None else 3.0e38, 0, 0, 0], device=dev, dtype=torch.float32)
     l1, l2, l3 = m.net[0], m.net[2], m.net[4]
     Wh = torch.zeros(16, 64, device=dev); Wh[:12] = m.mean_layer.weight.detach(); Wh[12] = m.value_layer.weight.detach()[0]
@@ -62,11 +64,11 @@ def pack_mlp_params(m: SharedMLP, obs_mean=None, obs_var=None, eps=1e-8, clip=5.
 def mlp_forward_hip(obs: torch.Tensor, packed: torch.Tensor):
     from ..lib import load_library
     lib = load_library()
-    assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == 64
-    assert packed.is_cuda and packed.numel() == lib.lm_mlp_param_count()
+    assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] in (64, 88)
+    assert packed.is_cuda and packed.numel() == lib.lm_mlp_param_count_obs(obs.shape[1])
     B = obs.shape[0]
     mean = torch.empty((B, 12), device=obs.device); value = torch.empty((B, 1), device=obs.device)
-    rc = lib.lm_mlp_forward(C.c_void_p(obs.data_ptr()), B, C.c_void_p(packed.data_ptr()), C.c_void_p(mean.data_ptr()),
+    rc = lib.lm_mlp_forward_obs(C.c_void_p(obs.data_ptr()), B, obs.shape[1], C.c_void_p(packed.data_ptr()), C.c_void_p(mean.data_ptr()),
                             C.c_void_p(value.data_ptr()), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"lm_mlp_forward failed ({rc})")

@@ -60,8 +60,9 @@ class PPO:
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.n_obs = int(env.observation_space.shape[0])          # 88 for the custom-controller tasks
         self.obs_scaler = RunningStandardScaler(self.n_obs, self.dev); self.val_scaler = RunningStandardScaler(1, self.dev)
-        # the MFMA forward kernels take the 64-wide observation; wider observations use the torch modules for rollouts too
-        self.hip = hip_inference and hasattr(model, "act_inference") and torch.cuda.is_available() and self.n_obs == 64
+        # MFMA forward kernels: MLP on the 64- and 88-wide observations, GNN on the 64-wide one
+        self.hip = hip_inference and hasattr(model, "act_inference") and torch.cuda.is_available() and \
+            (self.n_obs == 64 or (self.n_obs == 88 and type(model).__name__ == "SharedMLP"))
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=self.dev, dtype=dt)
         self.b_obs, self.b_act, self.b_logp = z(self.T, self.N, self.n_obs), z(self.T, self.N, 12), z(self.T, self.N)
         self.b_val, self.b_rew, self.b_done = z(self.T, self.N), z(self.T, self.N), z(self.T, self.N)

@@ -188,3 +188,40 @@ def test_fused_rollout_graph_equals_stepwise(policy):
     assert np.abs(lp - ro_plain.logp.reshape(-1).cpu().numpy()).max() < 2e-4
     for r in (ro_graph, ro_plain): r.close()
     for e in engines: e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nobs", [64, 88])
+def test_mlp_forward_matches_torch_for_both_observation_widths(nobs):
+    """MLP trunk 64-256-128-64 + heads on fp32 MFMA (4 wavefronts per 16-sample tile) against the torch modules, with the running
+    observation scaler folded in; 88 = the custom-controller observation (…custom_controller.py:432-455)."""
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params, mlp_forward_hip
+    torch.manual_seed(nobs)
+    m = SharedMLP(num_observations=nobs).cuda()
+    mean, var = torch.randn(nobs, device="cuda") * 0.3, torch.rand(nobs, device="cuda") + 0.2
+    packed = pack_mlp_params(m, mean, var, 1e-8, 5.0)
+    for B in (16, 4096, 4101):
+        obs = torch.randn(B, nobs, device="cuda") * 2
+        mu, v = mlp_forward_hip(obs, packed)
+        with torch.no_grad():
+            x = torch.clamp((obs - mean) / (var.sqrt() + 1e-8), -5, 5)
+            mu_t, _, v_t = m(x)
+        assert (mu - mu_t).abs().max() < 2e-5 and (v - v_t).abs().max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_fused_rollout_on_a_custom_controller_task():
+    """88-wide observations: the fused rollout runs the custom-controller task with the MLP on MFMA (f-1 x f-2)."""
+    import locomanipulationrl_amd as lm
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params, mlp_forward_hip
+    env = lm.make_env("QuadrupedPoseControlCustomController", num_envs=256)
+    obs = env.reset()["obs"]
+    m = SharedMLP(num_observations=88).cuda(); packed = pack_mlp_params(m).cuda(); log_std = torch.full((12,), -1.0, device="cuda")
+    ro = env._task.make_rollout("mlp", packed, log_std, T=8, noise_seed=5)
+    assert ro.obs.shape == (9, 256, 88)
+    ro.obs[0].copy_(obs); ro.run(); torch.cuda.synchronize()
+    mu, v = mlp_forward_hip(ro.obs[3].contiguous(), packed)
+    assert torch.equal(v.reshape(-1), ro.values[3]) and torch.isfinite(ro.obs).all() and float(ro.actions.abs().max()) > 0
+    eps = (ro.actions[3] - mu) / log_std.exp()
+    assert abs(float(eps.mean())) < 0.1 and abs(float(eps.std()) - 1.0) < 0.1
+    ro.close(); env.close()
