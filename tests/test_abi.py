@@ -36,16 +36,18 @@ def test_exports_match_header(so):
 
 
 def test_params_struct_layout_matches_c():
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "lm_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(lm_params), ' \
-          'offsetof(lm_params, substeps), offsetof(lm_params, init_q), offsetof(lm_params, corner), offsetof(lm_params, plate_phi));return 0;}\n'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "lm_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lm_params), ' \
+          'offsetof(lm_params, substeps), offsetof(lm_params, init_q), offsetof(lm_params, corner), offsetof(lm_params, plate_phi), ' \
+          'offsetof(lm_params, variant), offsetof(lm_params, dr), offsetof(lm_params, acc_dt_inv), sizeof(lm_dr_channel));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c"); open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        size, o_sub, o_q, o_corner, o_phi = map(int, subprocess.check_output([exe]).split())
+        size, o_sub, o_q, o_corner, o_phi, o_var, o_dr, o_acc, s_ch = map(int, subprocess.check_output([exe]).split())
     P = lmlib.LmParams
-    assert C.sizeof(P) == size
+    assert C.sizeof(P) == size and C.sizeof(lmlib.LmDrChannel) == s_ch
     assert (P.substeps.offset, P.init_q.offset, P.corner.offset, P.plate_phi.offset) == (o_sub, o_q, o_corner, o_phi)
+    assert (P.variant.offset, P.dr.offset, P.acc_dt_inv.offset) == (o_var, o_dr, o_acc)
 
 
 def test_argument_validation_without_gpu(so):
@@ -65,3 +67,14 @@ def test_argument_validation_without_gpu(so):
     assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), arr, 2, 24, 0) == -1     # split not a multiple of 16
     bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(dt=0.0)))
     assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1
+    bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(variant=1)))                    # custom controller needs the 88-wide observation
+    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1 and b"variant" in so.lm_last_error()
+    from locomanipulationrl_amd.engine_config import DRChannel
+    dr = [DRChannel() for _ in range(8)]; dr[1] = DRChannel(enabled=1, operation=0, distribution=0, interval=0)      # on_interval noise without an interval
+    bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(dr_enabled=1, dr=dr)))
+    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1 and b"randomisation" in so.lm_last_error()
+    # policy / rollout entry points
+    assert so.lm_mlp_param_count_obs(64) == so.lm_mlp_param_count() and so.lm_mlp_param_count_obs(88) > so.lm_mlp_param_count() and so.lm_mlp_param_count_obs(70) == -1
+    assert so.lm_rollout_create(None, None, 0, None, None, 0, 0, None, None, None, None, None, None, None) == -1
+    assert so.lm_rollout_run(None, 1, None) == -1 and so.lm_rollout_destroy(None) == 0
+    assert so.lm_sample_actions(None, None, None, 0, 0, None, None, None) == -1
