@@ -8,7 +8,9 @@
 // per-task constants are read through scalar loads.  DESIGN.md sections 3-5 derive every formula.
 //
 // Reference rows replaced: a4-a6 (reset scatter + action scaling), a7 (PhysX world.step x
-// controlFrequencyInv), a8 (state read-back), a9-a11 (obs / reward / termination), a13 (plate deltas).
+// controlFrequencyInv), a8 (state read-back), a9-a11 (obs / reward / termination), a13 (plate deltas), a14 (co-train:
+// two parameter blocks in one launch); 8f-1 (PD-actuator task families = template parameter VAR of the step), 8f-3 (domain
+// randomisation = template parameter DR, kernel k_step_dr); reductions over envs are fused into the step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -21,7 +23,6 @@
 #define HUB_FLOATS 10
 #define LIMB_STRIDE 119
 #define ENVS_PER_WAVE 16
-#define NPART 12           // per-block partial sums: 7 reward terms, goal_reset, reset, 3 custom-controller terms
 
 // state rows
 #define R_FB0 0            // base: pos 0..2 quat 3..6 lin 7..9 ang 10..12
