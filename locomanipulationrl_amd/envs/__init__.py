@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/envs (MI355X loco-manipulation step engine)."""

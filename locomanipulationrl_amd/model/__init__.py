@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/model (MI355X loco-manipulation step engine)."""

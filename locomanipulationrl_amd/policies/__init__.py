@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/policies (MI355X loco-manipulation step engine)."""

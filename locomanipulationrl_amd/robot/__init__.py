@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/robot (MI355X loco-manipulation step engine)."""

@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/tasks (MI355X loco-manipulation step engine)."""

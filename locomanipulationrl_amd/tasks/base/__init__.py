@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/tasks/base (MI355X loco-manipulation step engine)."""

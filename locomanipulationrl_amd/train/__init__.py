@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/train (MI355X loco-manipulation step engine)."""

@@ -1,0 +1,1 @@
+"""locomanipulationrl_amd/utils (MI355X loco-manipulation step engine)."""

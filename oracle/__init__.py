@@ -1,0 +1,1 @@
+"""oracle (MI355X loco-manipulation step engine)."""
