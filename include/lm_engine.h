@@ -48,9 +48,10 @@ extern "C" {
  * (operation / distribution / distribution_parameters [/ frequency_interval]).  Observation and action noise follow
  * utils/domain_randomization/randomize.py:212-306 (wrapper call sites vec_env_rlgames.py:56-58,70-72); the physics attributes are
  * sampled per env inside lm_step (the reference delegates them to omni.replicator.isaac; semantics in DESIGN.md 3.6). */
-#define LM_DR_CHANNELS 8
+#define LM_DR_CHANNELS 9
 enum { LM_DR_OBS_RESET = 0, LM_DR_OBS_INTERVAL = 1, LM_DR_ACT_RESET = 2, LM_DR_ACT_INTERVAL = 3,
-       LM_DR_GRAVITY = 4, LM_DR_BASE_FORCE = 5, LM_DR_MAX_EFFORT = 6, LM_DR_MAX_VELOCITY = 7 };
+       LM_DR_GRAVITY = 4, LM_DR_BASE_FORCE = 5, LM_DR_MAX_EFFORT = 6, LM_DR_MAX_VELOCITY = 7,
+       LM_DR_JOINT_DAMPING = 8 /* articulation `damping` of the PD-actuator tasks (variants 1 / 2): scales joint_damping */ };
 enum { LM_DR_ADDITIVE = 0, LM_DR_SCALING = 1, LM_DR_DIRECT = 2 };
 enum { LM_DR_GAUSSIAN = 0, LM_DR_UNIFORM = 1, LM_DR_LOGUNIFORM = 2 };
 typedef struct lm_dr_channel {
@@ -60,6 +61,7 @@ typedef struct lm_dr_channel {
   int32_t interval;        /* frequency_interval of an on_interval entry (>= 1); 0 = on_reset entry */
   float p0[3], p1[3];      /* distribution_parameters: mean / std or low / high (one pair per component for gravity and force) */
 } lm_dr_channel;
+#define LM_DR_PHYS_ROWS 42
 #define LM_DR_CNT_ROWS 5   /* int64 [row][N]: observation noise counter, action noise counter, dr_step, randomization_buf, dr_reset_key */
 
 typedef struct lm_params {
@@ -109,7 +111,8 @@ typedef enum {
   LM_PTR_STATS = 6,     /* int64 [6] {num_successes, num_resets} x {all, task 0, task 1}; float [3] rates at byte 48 */
   LM_PTR_TERMS = 7,     /* float [LM_TERM_ROWS][N]  per-env reward terms of the last step */
   LM_PTR_DR_CNT = 8,    /* int64 [LM_DR_CNT_ROWS][N]  domain-randomisation counters */
-  LM_PTR_DR_PHYS = 9    /* float [30][N]  attributes sampled for the last step: max efforts 12, max joint velocities 12, gravity 3, base force 3 */
+  LM_PTR_DR_PHYS = 9    /* float [LM_DR_PHYS_ROWS][N]  attributes sampled for the last step: max efforts 12, max joint velocities 12,
+                           gravity 3, base force 3, joint damping 12 */
 } lm_ptr_kind;
 
 /* Create an engine for n_envs environments on the current HIP device.

@@ -98,7 +98,7 @@ LM_DEV float dr_attr(const lm_dr_channel& ch, uint32_t seed, uint32_t stream, in
   if (ch.interval == 0 && key == 0) return base;
   return dr_apply(ch.operation, base, dr_sample(seed, stream, (uint32_t)env, key, (uint32_t)idx, ch.distribution, ch.p0[comp], ch.p1[comp]));
 }
-struct DrPhys { float tmax[3], vmax[3]; V3 g, f; };      // this lane's three joints; gravity (world); base-link force (world)
+struct DrPhys { float tmax[3], vmax[3], cj[3]; V3 g, f; };      // this lane's three joints; gravity (world); base-link force (world)
 LM_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
   float sy, cy, sr, cr, sp, cp;
   sincosf(yaw * 0.5f, &sy, &cy); sincosf(roll * 0.5f, &sr, &cr); sincosf(pitch * 0.5f, &sp, &cp);
@@ -321,7 +321,8 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
 template <int MODE, int VAR, int DR>
 LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const float* tl, int limb, const Stash& St,
                     FreeBody& F, const M3& Rfix, V3 pfix, float q[3], float qd[3], const float tgt[3], float tau_acc[3], const DrPhys& X) {
-  const float dt = P->dt, kd = P->kd, cj = VAR ? P->joint_damping : 0.f;
+  const float dt = P->dt, kd = P->kd;
+  const float cjv[3] = {VAR ? (DR ? X.cj[0] : P->joint_damping) : 0.f, VAR ? (DR ? X.cj[1] : P->joint_damping) : 0.f, VAR ? (DR ? X.cj[2] : P->joint_damping) : 0.f};
   const float tmax[3] = {DR ? X.tmax[0] : P->tau_max, DR ? X.tmax[1] : P->tau_max, DR ? X.tmax[2] : P->tau_max};
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
   float bn;
@@ -403,6 +404,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     const int di[3] = {0, 3, 5};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
+      const float cj = cjv[a];
       if (!sat[a]) { Ha[di[a]] += dt * (kd + cj); r[a] = kd * (tgt[a] - qd[a]) - cj * qd[a] - hq[a]; }
       else { Ha[di[a]] += dt * cj; r[a] = tsat[a] - cj * qd[a] - hq[a]; }      // viscous joint damping is implicit in both cases
     }
@@ -774,7 +776,7 @@ struct StepArgs {
   int skip_reset;   // 1: leave reset_buf untouched (staged API: resets were applied by lm_apply_resets)
   int nsub;         // < 0: params.substeps, otherwise that many sub-steps (0 = read-back + task layer only)
   int64_t* drc;     // domain-randomisation counters [LM_DR_CNT_ROWS][N] (k_step_dr only)
-  float* dr_phys;   // [30][N] attributes sampled for this step (k_step_dr only)
+  float* dr_phys;   // [LM_DR_PHYS_ROWS][N] attributes sampled for this step (k_step_dr only)
 };
 
 template <int MODE, int VAR, int DR>
@@ -827,12 +829,13 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
       fv[c] = dr_attr(P->dr[LM_DR_BASE_FORCE], A.seed, LM_DR_BASE_FORCE, env, dr_step, (uint32_t)dr_reset_key, c, c, 0.f);
       X.tmax[c] = dr_attr(P->dr[LM_DR_MAX_EFFORT], A.seed, LM_DR_MAX_EFFORT, env, dr_step, (uint32_t)dr_reset_key, jj[c], 0, P->tau_max);
       X.vmax[c] = dr_attr(P->dr[LM_DR_MAX_VELOCITY], A.seed, LM_DR_MAX_VELOCITY, env, dr_step, (uint32_t)dr_reset_key, jj[c], 0, P->max_joint_vel);
+      X.cj[c] = dr_attr(P->dr[LM_DR_JOINT_DAMPING], A.seed, LM_DR_JOINT_DAMPING, env, dr_step, (uint32_t)dr_reset_key, jj[c], 0, P->joint_damping);
     }
     X.g = v3(gv[0], gv[1], gv[2]); X.f = v3(fv[0], fv[1], fv[2]);
     if (active) {
       float* ph = A.dr_phys;
 #pragma unroll
-      for (int c = 0; c < 3; c++) { ph[(size_t)jj[c] * N + env] = X.tmax[c]; ph[(size_t)(12 + jj[c]) * N + env] = X.vmax[c]; }
+      for (int c = 0; c < 3; c++) { ph[(size_t)jj[c] * N + env] = X.tmax[c]; ph[(size_t)(12 + jj[c]) * N + env] = X.vmax[c]; ph[(size_t)(30 + jj[c]) * N + env] = X.cj[c]; }
       if (limb == 0) {
 #pragma unroll
         for (int c = 0; c < 3; c++) { ph[(size_t)(24 + c) * N + env] = gv[c]; ph[(size_t)(27 + c) * N + env] = fv[c]; }
@@ -1264,7 +1267,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_state, LM_STATE_ROWS * N * sizeof(float));
   ALLOC(h->d_cnt, LM_CNT_ROWS * N * sizeof(int64_t));
   ALLOC(h->d_drc, LM_DR_CNT_ROWS * N * sizeof(int64_t));
-  ALLOC(h->d_dr_phys, 30 * N * sizeof(float));
+  ALLOC(h->d_dr_phys, LM_DR_PHYS_ROWS * N * sizeof(float));
   ALLOC(h->d_obs, N * (size_t)h->num_obs * sizeof(float));
   ALLOC(h->d_states, N * 93 * sizeof(float));
   ALLOC(h->d_rew, N * sizeof(float));

@@ -31,8 +31,8 @@ def _f(x):
 
 
 # ---- domain randomisation (YAML schema of cfg/task/QuadrupedPoseControl.yaml:102-173)
-DR_OBS_RESET, DR_OBS_INTERVAL, DR_ACT_RESET, DR_ACT_INTERVAL, DR_GRAVITY, DR_BASE_FORCE, DR_MAX_EFFORT, DR_MAX_VELOCITY = range(8)
-DR_CHANNELS = 8
+DR_OBS_RESET, DR_OBS_INTERVAL, DR_ACT_RESET, DR_ACT_INTERVAL, DR_GRAVITY, DR_BASE_FORCE, DR_MAX_EFFORT, DR_MAX_VELOCITY, DR_JOINT_DAMPING = range(9)
+DR_CHANNELS = 9
 DR_OPERATIONS = {"additive": 0, "scaling": 1, "direct": 2}
 DR_DISTRIBUTIONS = {"gaussian": 0, "normal": 0, "uniform": 1, "loguniform": 2, "log_uniform": 2}
 

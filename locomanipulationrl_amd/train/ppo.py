@@ -153,8 +153,9 @@ class PPO:
             if self.world > 1:
                 dist.all_reduce(kl); kl /= self.world
             kl = float(kl)                                                        # KLAdaptiveRL (skrl): lr /= 1.5 above 2*thr, *= 1.5 below thr/2
-            if kl > self.kl_thr * 2: self.lr = max(self.lr / 1.5, 1e-6)
-            elif kl < self.kl_thr / 2: self.lr = min(self.lr * 1.5, 1e-2)
+            if self.kl_thr > 0:                                                   # kl_threshold 0 = fixed learning rate
+                if kl > self.kl_thr * 2: self.lr = max(self.lr / 1.5, 1e-6)
+                elif kl < self.kl_thr / 2: self.lr = min(self.lr * 1.5, 1e-2)
             for gp in self.opt.param_groups: gp["lr"] = self.lr
             stats = {"kl": kl, "loss_pi": float(loss_pi), "loss_v": float(loss_v), "lr": self.lr}
         return stats

@@ -15,7 +15,10 @@ Supported entries (everything the reference's YAMLs enable):
     rigid_prim_views.<base link>.force                 "
     articulation_views.<robot>.max_efforts             "   (scalar parameters, one draw per joint)
     articulation_views.<robot>.joint_max_velocities    "
-Anything else (scale, mass, density, material_properties, joint_friction, damping, stiffness ...) raises NotImplementedError when
+    articulation_views.<robot>.damping                 "   (the viscous joint damping of the PD-actuator tasks; no effect on velocity-drive tasks,
+                                                           whose joint_damping is 0)
+    articulation_views.<robot>.joint_friction          accepted and ignored with a warning (joint friction itself is not modelled)
+Anything else (scale, mass, density, material_properties, stiffness ...) raises NotImplementedError when
 `randomize: True` - a silently ignored randomisation would be worse than a loud one."""
 from __future__ import annotations
 
@@ -23,7 +26,7 @@ from typing import List
 
 import numpy as np
 
-from ...engine_config import (DR_ACT_INTERVAL, DR_ACT_RESET, DR_BASE_FORCE, DR_CHANNELS, DR_DISTRIBUTIONS, DR_GRAVITY, DR_MAX_EFFORT,
+from ...engine_config import (DR_ACT_INTERVAL, DR_ACT_RESET, DR_BASE_FORCE, DR_CHANNELS, DR_DISTRIBUTIONS, DR_GRAVITY, DR_JOINT_DAMPING, DR_MAX_EFFORT,
                               DR_MAX_VELOCITY, DR_OBS_INTERVAL, DR_OBS_RESET, DR_OPERATIONS, DRChannel)
 
 _ON_RESET_KEYS = ("operation", "distribution", "distribution_parameters")
@@ -115,7 +118,11 @@ class Randomizer:
                     for attribute, entry in (attrs or {}).items():
                         if attribute == "scale":
                             continue
-                        ch = {"max_efforts": DR_MAX_EFFORT, "joint_max_velocities": DR_MAX_VELOCITY}.get(attribute)
+                        if attribute == "joint_friction":          # the joint friction coefficient itself is not modelled: scaling it changes nothing
+                            import warnings
+                            warnings.warn(f"articulation_views.{view}.joint_friction: joint friction is not modelled by this engine; entry ignored")
+                            continue
+                        ch = {"max_efforts": DR_MAX_EFFORT, "joint_max_velocities": DR_MAX_VELOCITY, "damping": DR_JOINT_DAMPING}.get(attribute)
                         if ch is None:
                             raise NotImplementedError(f"domain randomisation of articulation_views.{view}.{attribute} is not implemented")
                         self._set_up_attribute(("articulation_views", view, attribute), entry, ch, vector=False)

@@ -110,7 +110,7 @@ void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_inter
   }
 }
 
-typedef struct { real tmax[12], vmax[12], g[3], f[3]; } env_dr_t;
+typedef struct { real tmax[12], vmax[12], g[3], f[3], cj[12]; } env_dr_t;
 static __thread const env_dr_t* g_dr = 0;      /* per-env physics overrides while lmo_step_dr runs a sub-step */
 
 /* ------------------------------------------------------------------ kinematics */
@@ -333,7 +333,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     real L[NU][NU]; memcpy(L, D->M, sizeof(L)); real rhs[NU];
     for (int a=0;a<NU;a++) rhs[a]=-D->h[a];
     for (int j=0;j<12;j++) { if (!sat[j]) { L[6+j][6+j]+=dt*kd; rhs[6+j]+=kd*(target[j]-u[6+j]); } else rhs[6+j]+=tsat[j];
-      L[6+j][6+j]+=dt*cj; rhs[6+j]-=cj*u[6+j]; }       /* viscous joint damping, implicit */
+      { real cjj=g_dr?g_dr->cj[j]:cj; L[6+j][6+j]+=dt*cjj; rhs[6+j]-=cjj*u[6+j]; } }       /* viscous joint damping, implicit */
     chol(L);
     real acc[NU], uf[NU]; chol_solve(L, rhs, acc); for (int a=0;a<NU;a++) uf[a]=u[a]+dt*acc[a];
     real MiJ[12][NU], W[12][12], vf[12], lam[12];
@@ -628,8 +628,9 @@ void lmo_step_dr(const lmo_model* m, const lmo_params* p, int N, real* phys, rea
     for (int c=0;c<3;c++) { x->g[c]=dr_attr(&p->dr[LMO_DR_GRAVITY], seed, LMO_DR_GRAVITY, e, d, c, c, g0[c]);
                             x->f[c]=dr_attr(&p->dr[LMO_DR_BASE_FORCE], seed, LMO_DR_BASE_FORCE, e, d, c, c, 0); }
     for (int j=0;j<12;j++) { x->tmax[j]=dr_attr(&p->dr[LMO_DR_MAX_EFFORT], seed, LMO_DR_MAX_EFFORT, e, d, j, 0, (real)p->tau_max);
-                             x->vmax[j]=dr_attr(&p->dr[LMO_DR_MAX_VELOCITY], seed, LMO_DR_MAX_VELOCITY, e, d, j, 0, (real)p->max_joint_vel); }
-    if (physdr) { real* o=physdr+(size_t)e*30; for (int j=0;j<12;j++){o[j]=x->tmax[j];o[12+j]=x->vmax[j];} for (int c=0;c<3;c++){o[24+c]=x->g[c];o[27+c]=x->f[c];} }
+                             x->vmax[j]=dr_attr(&p->dr[LMO_DR_MAX_VELOCITY], seed, LMO_DR_MAX_VELOCITY, e, d, j, 0, (real)p->max_joint_vel);
+                             x->cj[j]=dr_attr(&p->dr[LMO_DR_JOINT_DAMPING], seed, LMO_DR_JOINT_DAMPING, e, d, j, 0, (real)p->joint_damping); }
+    if (physdr) { real* o=physdr+(size_t)e*42; for (int j=0;j<12;j++){o[j]=x->tmax[j];o[12+j]=x->vmax[j];o[30+j]=x->cj[j];} for (int c=0;c<3;c++){o[24+c]=x->g[c];o[27+c]=x->f[c];} }
   }
   /* 4./5. the step itself */
   step_core(m, p, N, phys, task, cnt, act, goal_rand, seed, obs, states, rew, terms, drs);

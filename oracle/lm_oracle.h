@@ -56,9 +56,9 @@ typedef struct {
   int32_t knee_body[8];
 } lmo_model;
 
-#define LMO_DR_CHANNELS 8
+#define LMO_DR_CHANNELS 9
 enum { LMO_DR_OBS_RESET = 0, LMO_DR_OBS_INTERVAL, LMO_DR_ACT_RESET, LMO_DR_ACT_INTERVAL, LMO_DR_GRAVITY, LMO_DR_BASE_FORCE, LMO_DR_MAX_EFFORT,
-       LMO_DR_MAX_VELOCITY };
+       LMO_DR_MAX_VELOCITY, LMO_DR_JOINT_DAMPING };
 typedef struct {
   int32_t enabled;
   int32_t operation;       /* 0 additive, 1 scaling, 2 direct */
@@ -195,8 +195,8 @@ real lmo_dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, u
 void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_interval, uint32_t seed, uint32_t stream, int N, int D,
                   real* buf, const int64_t* reset_flags, int64_t* counter, const int64_t* corr_key, const int64_t* step_key);
 /* lmo_step with domain randomisation: raw (unclamped) actions in; obs_noisy = what VecEnvRLGames.step hands to the policy before
- * clamping (vec_env_rlgames.py:56-72).  drc = (N x LMO_DR_CNT) counters.  physdr (N x 30, may be NULL) receives the sampled
- * max efforts (12), max velocities (12), gravity (3), base force (3) */
+ * clamping (vec_env_rlgames.py:56-72).  drc = (N x LMO_DR_CNT) counters.  physdr (N x 42, may be NULL) receives the sampled
+ * max efforts (12), max velocities (12), gravity (3), base force (3), joint damping (12) */
 void lmo_step_dr(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt, int64_t* drc,
                  const real* actions_raw, real clip_actions, const real* goal_rand, uint32_t seed,
                  real* obs, real* states, real* rew, real* terms, real* actions_used, real* physdr);

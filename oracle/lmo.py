@@ -58,7 +58,7 @@ class LmoParams(C.Structure):
         ("variant", C.c_int32), ("num_obs", C.c_int32), ("pd_kp", C.c_double), ("joint_damping", C.c_double), ("act_scale_se", C.c_double),
         ("se_lo", C.c_double * 12), ("se_hi", C.c_double * 12), ("init_se", C.c_double * 12), ("torque_div", C.c_double),
         ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
-        ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmoDrChannel * 8),
+        ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmoDrChannel * 9),
     ]
 
 
@@ -198,12 +198,12 @@ class Oracle:
 
     def step_dr(self, phys, task, cnt, drc, actions_raw, clip_actions=1.0, goal_rand=None, seed=0):
         """lmo_step with domain randomisation; returns obs (noisy, unclipped), states, rew, terms, the clamped noisy actions and the
-        sampled physics attributes (N x 30: max efforts 12, max velocities 12, gravity 3, base force 3)."""
+        sampled physics attributes (N x 42: max efforts 12, max velocities 12, gravity 3, base force 3, joint damping 12)."""
         N = phys.shape[0]
         a = self._arr(actions_raw, (N, 12)); gr = None if goal_rand is None else self._arr(goal_rand, (N, 3))
         assert drc.dtype == np.int64 and drc.shape == (N, DR_CNT)
         obs = np.zeros((N, self._ep.num_obs), self.dtype); states = np.zeros((N, 93), self.dtype)
-        rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype); used = np.zeros((N, 12), self.dtype); phd = np.zeros((N, 30), self.dtype)
+        rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype); used = np.zeros((N, 12), self.dtype); phd = np.zeros((N, 42), self.dtype)
         cl = C.c_double(clip_actions) if self.dtype == np.float64 else C.c_float(clip_actions)
         self.lib.lmo_step_dr(C.byref(self.model), C.byref(self.params), C.c_int(N), self._p(phys), self._p(task), self._p(cnt), self._p(drc),
                              self._p(a), cl, None if gr is None else self._p(gr), C.c_uint32(seed),

@@ -182,9 +182,20 @@ def test_domain_randomisation_front_end():
         t.pre_physics_step(a)
     # anything the engine does not randomise is refused loudly instead of being ignored
     bad = {"task": {"domain_randomization": {"randomize": True, "randomization_params": {"articulation_views": {"robot_view": {
-        "damping": {"on_interval": {"frequency_interval": 300, "operation": "scaling", "distribution": "uniform", "distribution_parameters": [0.5, 1.5]}}}}}}}}
+        "stiffness": {"on_interval": {"frequency_interval": 300, "operation": "scaling", "distribution": "uniform", "distribution_parameters": [0.5, 1.5]}}}}}}}}
     with pytest.raises(NotImplementedError):
         make("QuadrupedPoseControl", 16, overrides=bad)
+    # the custom-controller DR block of the reference (cfg/task/QuadrupedPoseControlCustomControllerDR.yaml:150-170): damping is a channel,
+    # joint_friction (not modelled at all) is accepted with a warning
+    from locomanipulationrl_amd.engine_config import DR_JOINT_DAMPING
+    cc = {"task": {"domain_randomization": {"randomize": True, "min_frequency": 300, "randomization_params": {"articulation_views": {"robot_view": {
+        "damping": {"on_interval": {"frequency_interval": 300, "operation": "scaling", "distribution": "uniform", "distribution_parameters": [0.5, 1.5]}},
+        "joint_friction": {"on_interval": {"frequency_interval": 300, "operation": "scaling", "distribution": "uniform", "distribution_parameters": [0.5, 1.5]}}}}}}}}
+    with pytest.warns(UserWarning, match="joint friction is not modelled"):
+        envc = make("QuadrupedPoseControlCustomController", 16, overrides=cc)
+    ch = envc._task.engine_params()[0].dr[DR_JOINT_DAMPING]
+    assert ch.enabled == 1 and ch.interval == 300 and (ch.p0[0], ch.p1[0]) == (0.5, 1.5) and envc._task.engine_params()[0].dr_min_frequency == 300
+    envc.reset(); o, _, _, _ = envc.step(torch.zeros(16, 12)); assert torch.isfinite(o["obs"]).all()
     scale = {"task": {"domain_randomization": {"randomize": True, "randomization_params": {"articulation_views": {"robot_view": {
         "scale": {"on_startup": {"operation": "scaling", "distribution": "uniform", "distribution_parameters": [0.98, 1.02]}}}}}}}}
     with pytest.raises(NotImplementedError):

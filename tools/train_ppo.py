@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--task", default="QuadrupedPoseControl"); ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--timesteps", type=int, default=4800); ap.add_argument("--policy", default="mlp"); ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--out", default=""); ap.add_argument("--log-every", type=int, default=5)
+    ap.add_argument("--fixed-lr", action="store_true", help="no KL-adaptive learning rate (diagnostics; not the reference recipe)")
     ap.add_argument("--no-fused", action="store_true", help="drive the rollout step by step from Python instead of the captured hipGraph")
     a = ap.parse_args()
     local = int(os.environ.get("LOCAL_RANK", "0")); torch.cuda.set_device(local)
@@ -29,7 +30,7 @@ def main():
         model = SharedMLP(num_observations=env.observation_space.shape[0]).to(f"cuda:{local}"); hip = True
     if world > 1:
         for p in model.parameters(): torch.distributed.broadcast(p.data, 0)
-    ppo = PPO(env, model, hip_inference=hip, fused_rollout=not a.no_fused)
+    ppo = PPO(env, model, hip_inference=hip, fused_rollout=not a.no_fused, **({"kl_threshold": 0.0} if a.fixed_lr else {}))
     hist = ppo.train(a.timesteps, log_every=a.log_every, log=(lambda r: print(json.dumps(r), flush=True)) if rank == 0 else (lambda r: None))
     if rank == 0 and a.out:
         json.dump({"task": a.task, "num_envs": a.num_envs, "world": world, "policy": a.policy, "history": hist}, open(a.out, "w"), indent=1)
