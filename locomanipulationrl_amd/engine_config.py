@@ -170,12 +170,12 @@ def _cc(**kw):
 
 def loco_cc_params(**kw) -> EngineParams:
     """QuadrupedPoseControlCustomController: class-default pose, base at z 0.18, fixed goal yaw 1.57 (:67-78)."""
-    return replace(EngineParams(), **_cc(init_base_pos=[0.0, 0.0, 0.18], goal_lo=[0.0, 0.0, 1.57], goal_hi=[0.0, 0.0, 1.57], **kw))
+    return replace(EngineParams(), **_cc(**{**dict(init_base_pos=[0.0, 0.0, 0.18], goal_lo=[0.0, 0.0, 1.57], goal_hi=[0.0, 0.0, 1.57]), **kw}))
 
 
 def mani_cc_params(**kw) -> EngineParams:
     """QuadrupedManipulatePlateCustomController: plate dropped from z 0.18 onto the inverted fixed robot."""
-    return replace(EngineParams(mode=MODE_MANI), **_cc(init_plate_pos=[0.0, 0.0, 0.18], cc_update_last_tgt=0, **kw))
+    return replace(EngineParams(mode=MODE_MANI), **_cc(**{**dict(init_plate_pos=[0.0, 0.0, 0.18], cc_update_last_tgt=0), **kw}))
 
 
 _PC_INIT_SE = [-1.57, 1.57, 1.57, -1.57, -1.57, 1.05, 1.57, 1.05, 1.57, 1.05, -1.57, 1.05]
@@ -202,4 +202,4 @@ def loco_pc_params(**kw) -> EngineParams:
 def mani_pc_params(**kw) -> EngineParams:
     """QuadrupedManipulatePlatePositionControl: inverted fixed robot at z 0.3, plate dropped from z 0.44, 450-step episodes
     (quadruped_manipulate_plate_position_control.py:122-124,177; cfg/task/QuadrupedManipulatePlatePositionControl.yaml:18)."""
-    return replace(EngineParams(mode=MODE_MANI), **_pc(fixed_base_pos=[0.0, 0.0, 0.3], init_plate_pos=[0.0, 0.0, 0.44], max_episode=450, **kw))
+    return replace(EngineParams(mode=MODE_MANI), **_pc(**{**dict(fixed_base_pos=[0.0, 0.0, 0.3], init_plate_pos=[0.0, 0.0, 0.44], max_episode=450), **kw}))

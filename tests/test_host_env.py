@@ -163,7 +163,7 @@ def test_domain_randomisation_front_end():
     t = env._task
     assert t._dr_randomizer.randomize and t._dr_randomizer.min_frequency == 400 and t.randomize_actions and t.randomize_observations
     ep = t.engine_params()[0]
-    assert ep.dr_enabled == 1 and ep.dr_min_frequency == 400 and all(ch.enabled for ch in ep.dr)
+    assert ep.dr_enabled == 1 and ep.dr_min_frequency == 400 and all(ch.enabled for ch in ep.dr[:8]) and not ep.dr[8].enabled
     assert ep.dr[DR_OBS_RESET].p1[0] == 0.001 and ep.dr[DR_OBS_INTERVAL].p1[0] == 0.02 and ep.dr[DR_OBS_INTERVAL].interval == 1
     assert ep.dr[DR_ACT_RESET].p1[0] == 0.015 and ep.dr[DR_ACT_INTERVAL].p1[0] == 0.01
     assert ep.dr[DR_GRAVITY].interval == 400 and ep.dr[DR_GRAVITY].p1 == [0.1, 0.1, 0.5] and ep.dr[DR_GRAVITY].operation == 0
