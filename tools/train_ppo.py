@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=4800); ap.add_argument("--policy", default="mlp"); ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--out", default=""); ap.add_argument("--log-every", type=int, default=5)
     ap.add_argument("--fixed-lr", action="store_true", help="no KL-adaptive learning rate (diagnostics; not the reference recipe)")
+    ap.add_argument("--gnn-env-order", action="store_true", help="diagnostic: route GNN node k's output to the joint whose state node k reads (the reference feeds node order straight to the env)")
     ap.add_argument("--no-fused", action="store_true", help="drive the rollout step by step from Python instead of the captured hipGraph")
     a = ap.parse_args()
     local = int(os.environ.get("LOCAL_RANK", "0")); torch.cuda.set_device(local)
@@ -30,6 +31,12 @@ def main():
         model = SharedMLP(num_observations=env.observation_space.shape[0]).to(f"cuda:{local}"); hip = True
     if world > 1:
         for p in model.parameters(): torch.distributed.broadcast(p.data, 0)
+    if a.gnn_env_order:
+        inv = torch.empty(12, dtype=torch.long); 
+        for k in range(12): inv[k if k < 4 else (4 + 2 * (k - 4) if k < 8 else 5 + 2 * (k - 8))] = k
+        inv = inv.to(f"cuda:{local}"); _step = env.step
+        env.step = lambda act: _step(act[:, inv].contiguous())
+        a.no_fused = True
     ppo = PPO(env, model, hip_inference=hip, fused_rollout=not a.no_fused, **({"kl_threshold": 0.0} if a.fixed_lr else {}))
     hist = ppo.train(a.timesteps, log_every=a.log_every, log=(lambda r: print(json.dumps(r), flush=True)) if rank == 0 else (lambda r: None))
     if rank == 0 and a.out:
