@@ -82,12 +82,16 @@ LM_DEV void lm_sincos(float x, float* s, float* c) {
 
 // ---- domain randomisation: counter-based samples, same bits as oracle lmo_dr_sample up to fp32 rounding of log / cos
 LM_DEV float dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, uint32_t idx, int dist, float p0, float p1) {
+  // components 2p and 2p+1 share one pair of uniforms (Box-Muller's cosine and sine branches): calls for neighbouring components
+  // share the hashes, the logarithm, the square root and the sincos after common-subexpression elimination
+  const uint32_t pair = idx >> 1; const bool odd = (idx & 1U) != 0;
   uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ mix32(stream * 0x27D4EB2FU + 0x632BE5ABU));
-  uint32_t r1 = mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  uint32_t r1 = mix32(base + (2U * pair + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * pair + 2U) * 0xC2B2AE35U);
   float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
-  if (dist == LM_DR_GAUSSIAN) { float sn, cs; lm_sincos(6.283185307179586f * u2, &sn, &cs); return p0 + p1 * (sqrtf(-2.0f * logf(u1)) * cs); }
-  if (dist == LM_DR_UNIFORM) return p0 + (p1 - p0) * u2;
-  return expf(logf(p0) + (logf(p1) - logf(p0)) * u2);
+  if (dist == LM_DR_GAUSSIAN) { float sn, cs; lm_sincos(6.283185307179586f * u2, &sn, &cs); return p0 + p1 * (sqrtf(-2.0f * logf(u1)) * (odd ? sn : cs)); }
+  const float u = odd ? u1 - (1.0f / 16777216.0f) : u2;
+  if (dist == LM_DR_UNIFORM) return p0 + (p1 - p0) * u;
+  return expf(logf(p0) + (logf(p1) - logf(p0)) * u);
 }
 LM_DEV float dr_apply(int op, float x, float n) { return op == LM_DR_ADDITIVE ? x + n : (op == LM_DR_SCALING ? x * n : n); }
 // one randomised physics attribute: on_interval entries are redrawn every `interval` control steps, on_reset entries at the env's
@@ -696,10 +700,11 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
       const uint32_t ckey = DO.sKey[2 * el], fire = DO.sKey[2 * el + 1], e = (uint32_t)(env0 + el);
       const lm_dr_channel& cr = P->dr[LM_DR_OBS_RESET]; const lm_dr_channel& ci = P->dr[LM_DR_OBS_INTERVAL];
       float x[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t cpair = (uint32_t)col >> 1;          // col is a multiple of 4: components (col, col+1) and (col+2, col+3) are Box-Muller pairs
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if (cr.enabled) x[k] = dr_apply(cr.operation, x[k], dr_sample(DO.seed, LM_DR_OBS_RESET, e, ckey, (uint32_t)(col + k), cr.distribution, cr.p0[0], cr.p1[0]));
-        if (fire) x[k] = dr_apply(ci.operation, x[k], dr_sample(DO.seed, LM_DR_OBS_INTERVAL, e, DO.dr_step, (uint32_t)(col + k), ci.distribution, ci.p0[0], ci.p1[0]));
+        if (cr.enabled) x[k] = dr_apply(cr.operation, x[k], dr_sample(DO.seed, LM_DR_OBS_RESET, e, ckey, 2u * cpair + (uint32_t)k, cr.distribution, cr.p0[0], cr.p1[0]));
+        if (fire) x[k] = dr_apply(ci.operation, x[k], dr_sample(DO.seed, LM_DR_OBS_INTERVAL, e, DO.dr_step, 2u * cpair + (uint32_t)k, ci.distribution, ci.p0[0], ci.p1[0]));
       }
       v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
     }

@@ -79,13 +79,16 @@ int lmo_sizeof_real(void) { return (int)sizeof(real); }
 
 /* ------------------------------------------------------------------ domain randomisation: counter-based samples */
 real lmo_dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, uint32_t idx, int distribution, real p0, real p1) {
+  /* components 2p and 2p+1 share one pair of uniforms: Box-Muller's cosine and sine branches (two normals per logarithm) */
+  const uint32_t pair = idx >> 1, odd = idx & 1U;
   uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ mix32(stream * 0x27D4EB2FU + 0x632BE5ABU));
-  uint32_t r1 = mix32(base + (2U * idx + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * idx + 2U) * 0xC2B2AE35U);
+  uint32_t r1 = mix32(base + (2U * pair + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * pair + 2U) * 0xC2B2AE35U);
   real u1 = ((real)(r1 >> 8) + (real)1) * (real)(1.0 / 16777216.0);     /* (0, 1] */
   real u2 = (real)(r2 >> 8) * (real)(1.0 / 16777216.0);                 /* [0, 1) */
-  if (distribution == 0) return p0 + p1 * (real)(sqrt(-2 * log(u1)) * cos((real)6.283185307179586 * u2));     /* torch.normal(mean, std) */
-  if (distribution == 1) return p0 + (p1 - p0) * u2;                                                       /* (hi-lo)*rand + lo */
-  return (real)exp(log(p0) + (log(p1) - log(p0)) * u2);                                                      /* loguniform */
+  if (distribution == 0) { real rad = sqrt(-2 * log(u1)), ang = (real)6.283185307179586 * u2; return p0 + p1 * (real)(rad * (odd ? sin(ang) : cos(ang))); }   /* torch.normal(mean, std) */
+  real u = odd ? u1 - (real)(1.0 / 16777216.0) : u2;                     /* both in [0, 1) */
+  if (distribution == 1) return p0 + (p1 - p0) * u;                                                       /* (hi-lo)*rand + lo */
+  return (real)exp(log(p0) + (log(p1) - log(p0)) * u);                                                      /* loguniform */
 }
 
 static real dr_apply(int operation, real x, real n) { return operation == 0 ? x + n : (operation == 1 ? x * n : n); }
