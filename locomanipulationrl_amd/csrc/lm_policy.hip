@@ -287,18 +287,42 @@ __host__ __device__ constexpr int mlp_params(int nobs) { return mlp_off_bh(nobs)
 // the host permutation assumes (16 (st >> 2) + 4 g + (st & 3), i.e. "the previous layer's accumulator tile")
 template <bool NATURAL> __device__ __forceinline__ int mlp_krow(int st, int g) { return NATURAL ? 4 * st + g : 16 * (st >> 2) + 4 * g + (st & 3); }
 
+// The k-steps of all output blocks a wavefront owns form one sequence, processed in chunks of 16 with the next chunk's weights
+// (one coalesced 256-byte load per k-step) already in flight while the current chunk's MFMAs run: the loop is bound by the matrix
+// pipe, not by the L2 round trip of each chunk.
 template <int OUT_BLOCKS, int IN_STEPS, bool NATURAL>
 __device__ __forceinline__ void mlp_layer4(const float* __restrict__ Wp, const float* __restrict__ bias, const float* sIn, float* sOut,
                                            int wave, int lane, int n, int g, bool act) {
-  for (int mb = wave; mb < OUT_BLOCKS; mb += 4) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* wp = Wp + (size_t)mb * IN_STEPS * 64 + lane;
-    constexpr int UNR = (IN_STEPS % 16 == 0) ? 16 : 11;
-#pragma unroll UNR
-    for (int st = 0; st < IN_STEPS; st++)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(size_t)st * 64], sIn[mlp_krow<NATURAL>(st, g) * MLP_LDS_STRIDE + n], acc, 0, 0, 0);
+  constexpr int OWNED = (OUT_BLOCKS + 3) / 4, TOTAL = OWNED * IN_STEPS, CH = 16, NCH = (TOTAL + CH - 1) / CH;
+  if (wave >= OUT_BLOCKS) return;
+  float abuf[2][CH];
+  auto issue = [&](int c, float* dst) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) { float v = acc[i] + bias[16 * mb + 4 * g + i]; sOut[(16 * mb + 4 * g + i) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
+    for (int i = 0; i < CH; i++) {
+      const int s = c * CH + i;
+      if (s < TOTAL) { const int j = s / IN_STEPS, st = s - j * IN_STEPS, mb = wave + 4 * j; dst[i] = (mb < OUT_BLOCKS) ? Wp[((size_t)mb * IN_STEPS + st) * 64 + lane] : 0.f; }
+    }
+  };
+  issue(0, abuf[0]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (c + 1 < NCH) issue(c + 1, abuf[(c + 1) & 1]);
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      const int s = c * CH + i;
+      if (s < TOTAL) {
+        const int j = s / IN_STEPS, st = s - j * IN_STEPS, mb = wave + 4 * j;
+        if (mb < OUT_BLOCKS) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[c & 1][i], sIn[mlp_krow<NATURAL>(st, g) * MLP_LDS_STRIDE + n], acc, 0, 0, 0);
+          if (st == IN_STEPS - 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { float v = acc[k] + bias[16 * mb + 4 * g + k]; sOut[(16 * mb + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
+            acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    }
   }
 }
 
