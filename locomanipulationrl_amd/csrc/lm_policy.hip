@@ -69,10 +69,12 @@ struct SampleArgs { const float* log_std; const int64_t* cnt; uint32_t seed; flo
 
 // One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU.  Every wavefront OWNS a set of graph nodes: it keeps their features
 // in registers, computes their P / Q projections into LDS, and evaluates the messages along the edges that END in its nodes (max
-// aggregation is order independent, so the result is bit-identical to a single-wavefront evaluation).  Ownership balances the edges,
-// 6 per wavefront: {0,1} (4+2 incoming edges), {2,3,4} (2+2+2), {5,6,7} (2+2+2), {8,...,12} (2+1+1+1+1).
-__device__ __forceinline__ constexpr int gnn_first(int w) { return w == 0 ? 0 : (w == 1 ? 2 : (w == 2 ? 5 : 8)); }
-__device__ __forceinline__ constexpr int gnn_count(int w) { return w == 0 ? 2 : (w == 3 ? 5 : 3); }
+// aggregation is order independent, so the result is bit-identical to a single-wavefront evaluation).  Ownership balances the matrix work.
+// node j of wavefront w; MFMA count per layer = 32 per owned node + 16 per incoming edge: {0,1,9} 208, {2,3,4} 192, {5,6,7} 192, {8,10,11,12} 208
+__device__ __forceinline__ constexpr int gnn_count(int w) { return (w == 3) ? 4 : 3; }
+__device__ __forceinline__ constexpr int gnn_node(int w, int j) {
+  return w == 0 ? (j == 0 ? 0 : (j == 1 ? 1 : 9)) : (w == 1 ? 2 + j : (w == 2 ? 5 + j : (j == 0 ? 8 : 9 + j)));
+}
 // incoming edges of node t (graph_model_orebot_ov.py:142-159): hub <- its 4 dof1 nodes; dof1 <- hub, dof2; dof2 <- dof1, dof3; dof3 <- dof2
 __device__ __forceinline__ constexpr int gnn_nin(int t) { return t == 0 ? 4 : (t <= 8 ? 2 : 1); }
 __device__ __forceinline__ constexpr int gnn_in(int t, int k) { return t == 0 ? 1 + k : (t <= 4 ? (k == 0 ? 0 : t + 4) : (t <= 8 ? (k == 0 ? t - 4 : t + 4) : t - 4)); }
@@ -80,7 +82,7 @@ __device__ __forceinline__ constexpr int gnn_in(int t, int k) { return t == 0 ? 
 template <int WAVE>
 __device__ __forceinline__ void gnn_body(const float* __restrict__ obs, int B, const float* __restrict__ W, float* __restrict__ mean,
                                          float* __restrict__ value, const SampleArgs& SA, float* sPQ, float* sHm, float* sLp, int lane) {
-  constexpr int N0 = gnn_first(WAVE), NC = gnn_count(WAVE);
+  constexpr int NC = gnn_count(WAVE);
   const int n = lane & 15, g = lane >> 4;
   const int s0 = blockIdx.x * GNN_SAMPLES;
   const int sample = min(s0 + n, B - 1);
@@ -93,7 +95,7 @@ __device__ __forceinline__ void gnn_body(const float* __restrict__ obs, int B, c
   // ---- input layers (:97-104)
 #pragma unroll
   for (int j = 0; j < NC; j++) {
-    const int nd = N0 + j;
+    const int nd = gnn_node(WAVE, j);
     if (nd == 0) {      // hub node: Linear(16,32) on obs[0:16]
 #pragma unroll
       for (int mb = 0; mb < 2; mb++) {
@@ -149,7 +151,7 @@ __device__ __forceinline__ void gnn_body(const float* __restrict__ obs, int B, c
         for (int ob4 = 0; ob4 < 4; ob4++)
 #pragma unroll
           for (int i = 0; i < 4; i++)
-            sPQ[((N0 + j) * 64 + 16 * ob4 + 4 * g + i) * GNN_SAMPLES + n] = acc[ob4][i] + ((ob4 < 2) ? bias1[ob4][i] : 0.f);
+            sPQ[(gnn_node(WAVE, j) * 64 + 16 * ob4 + 4 * g + i) * GNN_SAMPLES + n] = acc[ob4][i] + ((ob4 < 2) ? bias1[ob4][i] : 0.f);
       }
     }
     __syncthreads();
@@ -167,7 +169,7 @@ __device__ __forceinline__ void gnn_body(const float* __restrict__ obs, int B, c
         for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
 #pragma unroll
       for (int j = 0; j < NC; j++) {
-        const int tgt = N0 + j;
+        const int tgt = gnn_node(WAVE, j);
         h[j][0] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; h[j][1] = h[j][0];
 #pragma unroll
         for (int k = 0; k < gnn_nin(tgt); k++) {
@@ -200,7 +202,7 @@ __device__ __forceinline__ void gnn_body(const float* __restrict__ obs, int B, c
   f32x4 hm0 = h[0][0], hm1 = h[0][1];
 #pragma unroll
   for (int j = 0; j < NC; j++) {
-    const int nd = N0 + j;
+    const int nd = gnn_node(WAVE, j);
 #pragma unroll
     for (int i = 0; i < 4; i++) { hm0[i] = fmaxf(hm0[i], h[j][0][i]); hm1[i] = fmaxf(hm1[i], h[j][1][i]); }
     if (nd == 0) continue;
