@@ -91,6 +91,8 @@ real lmo_dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t key, u
   return (real)exp(log(p0) + (log(p1) - log(p0)) * u);                                                      /* loguniform */
 }
 
+static uint32_t g_env0 = 0;      /* global id of the first env of the block being processed (co-training: the second half starts at N/2) */
+void lmo_set_env_offset(uint32_t env0) { g_env0 = env0; }
 static real dr_apply(int operation, real x, real n) { return operation == 0 ? x + n : (operation == 1 ? x * n : n); }
 
 void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_interval, uint32_t seed, uint32_t stream, int N, int D,
@@ -103,18 +105,19 @@ void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_inter
     /* :218-226: correlated noise, redrawn for the envs whose reset flag is set, applied to every env on every call */
     if (on_reset && on_reset->enabled)
       for (int j = 0; j < D; j++)
-        b[j] = dr_apply(on_reset->operation, b[j], lmo_dr_sample(seed, stream, (uint32_t)e, (uint32_t)corr_key[e], (uint32_t)j, on_reset->distribution, (real)on_reset->p0[0], (real)on_reset->p1[0]));
+        b[j] = dr_apply(on_reset->operation, b[j], lmo_dr_sample(seed, stream, g_env0 + (uint32_t)e, (uint32_t)corr_key[e], (uint32_t)j, on_reset->distribution, (real)on_reset->p0[0], (real)on_reset->p1[0]));
     /* :228-236: uncorrelated noise for the envs whose counter reached frequency_interval */
     if (on_interval && on_interval->enabled && counter[e] >= on_interval->interval) {
       counter[e] = 0;
       for (int j = 0; j < D; j++)
-        b[j] = dr_apply(on_interval->operation, b[j], lmo_dr_sample(seed, stream + 1U, (uint32_t)e, (uint32_t)step_key[e], (uint32_t)j, on_interval->distribution, (real)on_interval->p0[0], (real)on_interval->p1[0]));
+        b[j] = dr_apply(on_interval->operation, b[j], lmo_dr_sample(seed, stream + 1U, g_env0 + (uint32_t)e, (uint32_t)step_key[e], (uint32_t)j, on_interval->distribution, (real)on_interval->p0[0], (real)on_interval->p1[0]));
     }
   }
 }
 
 typedef struct { real tmax[12], vmax[12], g[3], f[3], cj[12]; } env_dr_t;
-static __thread const env_dr_t* g_dr = 0;      /* per-env physics overrides while lmo_step_dr runs a sub-step */
+static __thread const env_dr_t* g_dr = 0;
+      /* per-env physics overrides while lmo_step_dr runs a sub-step */
 
 /* ------------------------------------------------------------------ kinematics */
 typedef struct {
@@ -606,7 +609,7 @@ static real dr_attr(const lmo_dr_channel* ch, uint32_t seed, uint32_t stream, in
   if (!ch->enabled) return base;
   int64_t key = ch->interval > 0 ? d[2] / ch->interval : d[4];
   if (ch->interval == 0 && key == 0) return base;
-  real n = lmo_dr_sample(seed, stream, (uint32_t)e, (uint32_t)key, (uint32_t)idx, ch->distribution, (real)ch->p0[comp], (real)ch->p1[comp]);
+  real n = lmo_dr_sample(seed, stream, g_env0 + (uint32_t)e, (uint32_t)key, (uint32_t)idx, ch->distribution, (real)ch->p0[comp], (real)ch->p1[comp]);
   return dr_apply(ch->operation, base, n);
 }
 

@@ -197,6 +197,9 @@ void lmo_dr_noise(const lmo_dr_channel* on_reset, const lmo_dr_channel* on_inter
 /* lmo_step with domain randomisation: raw (unclamped) actions in; obs_noisy = what VecEnvRLGames.step hands to the policy before
  * clamping (vec_env_rlgames.py:56-72).  drc = (N x LMO_DR_CNT) counters.  physdr (N x 42, may be NULL) receives the sampled
  * max efforts (12), max velocities (12), gravity (3), base force (3), joint damping (12) */
+/* env ids feed the random stream: a block that is not at the start of the env range (the manipulation half of a co-training engine)
+ * sets the global id of its first env before calling lmo_dr_noise / lmo_step_dr (not thread safe: test infrastructure) */
+void lmo_set_env_offset(uint32_t env0);
 void lmo_step_dr(const lmo_model* m, const lmo_params* p, int N, real* phys, real* task, int64_t* cnt, int64_t* drc,
                  const real* actions_raw, real clip_actions, const real* goal_rand, uint32_t seed,
                  real* obs, real* states, real* rew, real* terms, real* actions_used, real* physdr);

@@ -196,7 +196,7 @@ class Oracle:
     def new_dr_counters(self, N):
         return np.zeros((N, DR_CNT), np.int64)
 
-    def step_dr(self, phys, task, cnt, drc, actions_raw, clip_actions=1.0, goal_rand=None, seed=0):
+    def step_dr(self, phys, task, cnt, drc, actions_raw, clip_actions=1.0, goal_rand=None, seed=0, env_offset=0):
         """lmo_step with domain randomisation; returns obs (noisy, unclipped), states, rew, terms, the clamped noisy actions and the
         sampled physics attributes (N x 42: max efforts 12, max velocities 12, gravity 3, base force 3, joint damping 12)."""
         N = phys.shape[0]
@@ -205,9 +205,11 @@ class Oracle:
         obs = np.zeros((N, self._ep.num_obs), self.dtype); states = np.zeros((N, 93), self.dtype)
         rew = np.zeros(N, self.dtype); terms = np.zeros((N, TERMS), self.dtype); used = np.zeros((N, 12), self.dtype); phd = np.zeros((N, 42), self.dtype)
         cl = C.c_double(clip_actions) if self.dtype == np.float64 else C.c_float(clip_actions)
+        self.lib.lmo_set_env_offset(C.c_uint32(env_offset))
         self.lib.lmo_step_dr(C.byref(self.model), C.byref(self.params), C.c_int(N), self._p(phys), self._p(task), self._p(cnt), self._p(drc),
                              self._p(a), cl, None if gr is None else self._p(gr), C.c_uint32(seed),
                              self._p(obs), self._p(states), self._p(rew), self._p(terms), self._p(used), self._p(phd))
+        self.lib.lmo_set_env_offset(C.c_uint32(0))
         return obs, states, rew, terms, used, phd
 
     def dr_noise(self, on_reset, on_interval, seed, stream, buf, reset_flags, counter, corr_key, step_key):

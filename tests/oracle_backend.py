@@ -73,7 +73,7 @@ class OracleEngine:
             g = gr[sl] if gr is not None else np.stack([o.hash_uniform3(self.seed, e, int(self.cntv[e, 5])) for e in range(sl.start, sl.stop)])
             if self.dr_enabled:
                 dc = self.drc[sl].copy()
-                ob, st, rw, tr, _, _ = o.step_dr(ph, tk, ct, dc, raw[sl], clip_actions=self.clip_actions, goal_rand=g, seed=self.seed)
+                ob, st, rw, tr, _, _ = o.step_dr(ph, tk, ct, dc, raw[sl], clip_actions=self.clip_actions, goal_rand=g, seed=self.seed, env_offset=sl.start)
                 self.drc[sl] = dc
             else:
                 ob, st, rw, tr = o.step(ph, tk, ct, a[sl], goal_rand=g, seed=self.seed)
