@@ -1,5 +1,5 @@
 /*
- * lm_policy.h -- C ABI of the GNN policy forward pass (part of liblm_engine.so).
+ * lm_policy.h -- C ABI of the policy forward passes (GNN, MLP), the action sampling and the fused rollout (part of liblm_engine.so).
  *
  * Replaces, for inference, the torch modules of RobotLearning/omniisaacgymenvs/scripts/graph_model_orebot_ov.py
  * (GraphNet :82-110, GraphLayer :11-80, Action_Layer :215-226, Value_Layer :228-241) as instantiated by

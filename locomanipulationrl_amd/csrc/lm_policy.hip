@@ -1,10 +1,12 @@
-// lm_policy.hip -- GNN policy forward on the matrix cores (gfx950).
+// lm_policy.hip -- policy forward passes on the matrix cores (gfx950): the GNN (below), the MLP, the gaussian action sampling
+// fused into their epilogues, and the fused rollout (forward -> sampling -> lm_step, T times, one hipGraph) of include/lm_policy.h.
 //
+// GNN:
 // Restates RobotLearning/omniisaacgymenvs/scripts/graph_model_orebot_ov.py:11-241 (GraphNet hidden 32, 13 nodes,
 // 24 directed edges, 3 message-passing layers with max aggregation, Action_Layer / Value_Layer heads) as one kernel:
 //   obs (B,64)  ->  action means (B,12) in node order [dof1 a1..a4, dof2 a1..a4, dof3 a1..a4], value (B,1).
 //
-// Mapping: one wavefront = 16 samples.  Every dense product runs as  D(features x samples) = W(features x K) * X(K x samples)
+// Mapping: one block = 16 samples on the four wavefronts of a CU (node ownership, see gnn_body).  Every dense product runs as  D(features x samples) = W(features x K) * X(K x samples)
 // on v_mfma_f32_16x16x4_f32 (exact fp32, = an fmaf chain), weights as the A operand, activations as the B operand, so an
 // accumulator tile (feature rows in the 4 registers / 4 lane groups, sample on the lane) feeds the next product's B operand
 // with no lane movement: only the k order inside the dot product is permuted, and the A operand is gathered in the same
