@@ -108,7 +108,8 @@ typedef enum {
   LM_PTR_STATES_BUF = 3,/* float [N][93]  task.states_buf                            */
   LM_PTR_REW_BUF = 4,   /* float [N]      task.rew_buf                               */
   LM_PTR_EXTRAS = 5,    /* float [LM_NUM_EXTRAS]  reward-term means + success rates     */
-  LM_PTR_STATS = 6,     /* int64 [6] {num_successes, num_resets} x {all, task 0, task 1}; float [3] rates at byte 48 */
+  LM_PTR_STATS = 6,     /* int64 [6] {num_successes, num_resets} x {all, task 0, task 1}; float [3] rates at byte 48;
+                           uint32 at byte 60: envs whose state became non-finite / exploded and was replaced by the reset pose */
   LM_PTR_TERMS = 7,     /* float [LM_TERM_ROWS][N]  per-env reward terms of the last step */
   LM_PTR_DR_CNT = 8,    /* int64 [LM_DR_CNT_ROWS][N]  domain-randomisation counters */
   LM_PTR_DR_PHYS = 9    /* float [LM_DR_PHYS_ROWS][N]  attributes sampled for the last step: max efforts 12, max joint velocities 12,

@@ -50,7 +50,8 @@ struct lm_engine {
   float* d_table;
   float* d_state; int64_t* d_cnt; int64_t* d_drc; float* d_dr_phys; int dr_enabled;
   float *d_obs, *d_states, *d_rew, *d_extras, *d_terms; long long* d_acc;
-  char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48
+  char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48;
+                           // uint32 count of contained blow-ups at byte 60
   lm_params h_params[2];
 };
 
@@ -941,6 +942,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
       const float* ip = (MODE == 0) ? P->init_base_pos : P->init_plate_pos; const float* iq = (MODE == 0) ? P->init_base_quat : P->init_plate_quat;
       F.p = v3(ip[0], ip[1], ip[2]); F.q.w = iq[0]; F.q.x = iq[1]; F.q.y = iq[2]; F.q.z = iq[3];
       F.u = sv(v3(0, 0, 0), v3(0, 0, 0));
+      if (active && limb == 0) atomicAdd(reinterpret_cast<unsigned int*>(A.W.stats + 60), 1u);      // contained blow-ups since creation (LM_PTR_STATS)
     }
   }
   // ---- read-back (robot.py:276-321)

@@ -203,8 +203,14 @@ class Engine:
         self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
         self.terms = self._wrap(PTR_TERMS, (TERM_ROWS, N), "<f4")
         self.stats_i64 = self._wrap(PTR_STATS, (6,), "<i8")
+        self._stats_i32 = self._wrap(PTR_STATS, (16,), "<i4")         # word 15: contained blow-ups
         self.dr_cnt = self._wrap(PTR_DR_CNT, (5, N), "<i8")          # domain-randomisation counters
         self.dr_phys = self._wrap(PTR_DR_PHYS, (42, N), "<f4")       # attributes sampled for the last step
+
+    @property
+    def blowups(self) -> int:
+        """Envs whose state became non-finite or exploded and was replaced by the reset pose (contained by the kernel's guard)."""
+        return int(self._stats_i32[15].item()) & 0xFFFFFFFF
 
     # ------------------------------------------------------------------
     def _check(self, rc: int):

@@ -335,6 +335,7 @@ def test_blowup_guard_forces_reset(robot_model, engine_cls):
     assert int(o1[3][5]) == 1 and int(o1[3][9]) == 1
     keep = [i for i in range(N) if i not in (5, 9)]
     assert torch.equal(o1[0][keep], o2[0][keep]) and torch.equal(o1[3][keep], o2[3][keep])
+    assert e1.blowups == 2 and e2.blowups == 0          # the guard counts what it contained (LM_PTR_STATS, word 15)
     for e in (e1, e2): e.close()
 
 
