@@ -324,6 +324,19 @@ class Engine:
     def get_cnt_env_major(self):
         return self.cnt.T.contiguous().cpu().numpy()
 
+    # ------------------------------------------------------------------ simulator checkpoint (the reference never
+    # checkpoints simulator state; with a deterministic engine a snapshot + the same actions reproduces a run bit for bit)
+    def state_dict(self):
+        """Everything lm_step reads besides its arguments: SoA state, counters, success windows, randomisation counters (host tensors)."""
+        self.torch.cuda.synchronize(self.device)
+        return {"state": self.state.cpu().clone(), "cnt": self.cnt.cpu().clone(), "stats": self._stats_i32.cpu().clone(),
+                "dr_cnt": self.dr_cnt.cpu().clone(), "num_envs": self.num_envs}
+
+    def load_state_dict(self, sd):
+        assert int(sd["num_envs"]) == self.num_envs and tuple(sd["state"].shape) == tuple(self.state.shape)
+        self.state.copy_(sd["state"].to(self.device)); self.cnt.copy_(sd["cnt"].to(self.device))
+        self._stats_i32.copy_(sd["stats"].to(self.device)); self.dr_cnt.copy_(sd["dr_cnt"].to(self.device))
+
 
 POLICY_MLP, POLICY_GNN = 0, 1
 

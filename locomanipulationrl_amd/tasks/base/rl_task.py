@@ -148,6 +148,13 @@ class RLTask:
             d.update({k: extras[10 + i] for i, k in enumerate(self.cc_extras_keys)})
         return d
 
+    def state_dict(self):
+        """Simulator checkpoint (engine state, counters, success windows, randomisation counters); see lib.Engine.state_dict."""
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd) -> None:
+        self.engine.load_state_dict(sd)
+
     def make_rollout(self, policy: str, packed_params: torch.Tensor, log_std: torch.Tensor, T: int, noise_seed: int = 0):
         """A fused T-step rollout (policy forward -> sampling -> step, one hipGraph launch; include/lm_policy.h)."""
         from ...lib import POLICY_GNN, POLICY_MLP, Rollout
