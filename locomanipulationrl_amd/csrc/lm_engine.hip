@@ -351,7 +351,11 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     V3 C0, C1, C2;        // contact axes (n, t1, t2) in hub coordinates
     float phi;
     if (MODE == 0) {
-      C0 = row2(Rb); C1 = row0(Rb); C2 = row1(Rb);
+      // contact axes in hub coordinates: n = world z; t1 = the base's x axis projected onto the ground plane, t2 = n x t1.  The friction
+      // basis turns with the robot, so the dynamics do not depend on its heading (exactly, even with the unconverged solver)
+      C0 = row2(Rb);
+      C1 = rsqrtf(fmaxf(1.0f - C0.x * C0.x, 1.0e-12f)) * v3(1.0f - C0.x * C0.x, -C0.x * C0.y, -C0.x * C0.z);
+      C2 = cross(C0, C1);
       phi = pb.z + dot(C0, D.x) - P->tip_radius;
     } else {
       V3 xw = pb + mul(Rb, D.x);

@@ -315,7 +315,11 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
   real Jc[12][NU], bn[4]; memset(Jc,0,sizeof(Jc));
   for (int i=0;i<4;i++) {
     real n[3], t1[3], t2[3], phi; real Jrel[3][NU]; memcpy(Jrel, D->Jt[i], sizeof(Jrel));
-    if (p->mode==0) { n[0]=0;n[1]=0;n[2]=1; t1[0]=1;t1[1]=0;t1[2]=0; t2[0]=0;t2[1]=1;t2[2]=0; phi=D->tip[i][2]-(real)p->tip_radius; }
+    if (p->mode==0) {
+      /* n = world z; t1 = the base's x axis projected onto the ground plane, t2 = n x t1: the friction basis turns with the robot,
+         so the dynamics do not depend on its heading */
+      real hx=D->R0[0], hy=D->R0[3], hn=sqrt(hx*hx+hy*hy); if (hn<(real)1e-6) hn=(real)1e-6;
+      n[0]=0;n[1]=0;n[2]=1; t1[0]=hx/hn;t1[1]=hy/hn;t1[2]=0; t2[0]=-t1[1];t2[1]=t1[0];t2[2]=0; phi=D->tip[i][2]-(real)p->tip_radius; }
     else {
       real d[3], y0[3], y[3]; for (int a=0;a<3;a++) d[a]=D->tip[i][a]-D->pf[a]; m3Tv(D->Rf, d, y0);
       for (int a=0;a<3;a++) y[a]=y0[a]-(real)p->plate_center[a];
