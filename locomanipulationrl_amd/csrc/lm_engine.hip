@@ -277,11 +277,19 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
   pgs_cross_blocks<2>(limb, T, B, G.Wf, G.X[2]); pgs_cross_blocks<3>(limb, T, B, G.Wf, G.X[3]);
   lam[0] = lam[1] = lam[2] = 0.f;
   float c[3] = {vf[0] + bn, vf[1], vf[2]};
-  for (int it = 0; it < iters; it++) {
+  // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
+  // ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
+  for (int it = 0; it < iters; it += 2) {
     pgs_turn<0>(limb, mu, G, lam, c);
     pgs_turn<1>(limb, mu, G, lam, c);
     pgs_turn<2>(limb, mu, G, lam, c);
     pgs_turn<3>(limb, mu, G, lam, c);
+    if (it + 1 < iters) {
+      pgs_turn<3>(limb, mu, G, lam, c);
+      pgs_turn<2>(limb, mu, G, lam, c);
+      pgs_turn<1>(limb, mu, G, lam, c);
+      pgs_turn<0>(limb, mu, G, lam, c);
+    }
   }
   // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
   w = quad_sum(fma6(lam[0], B[0], fma6(lam[1], B[1], lam[2] * B[2])));

@@ -351,7 +351,8 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     for (int r=0;r<12;r++) { for (int c=0;c<12;c++){ real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*MiJ[c][a]; W[r][c]=s; }
       real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*uf[a]; vf[r]=s; lam[r]=0; }
     if (g_cap_W) { for (int r=0;r<12;r++) { for (int c=0;c<12;c++) g_cap_W[12*r+c]=W[r][c]; g_cap_vf[r]=vf[r]; } for (int i=0;i<4;i++) g_cap_bn[i]=bn[i]; }
-    for (int it=0; it<p->pgs_iters; it++) for (int i=0;i<4;i++) {
+    for (int it=0; it<p->pgs_iters; it++) for (int ii=0;ii<4;ii++) {
+      const int i=(it&1)?3-ii:ii;      /* sweeps alternate direction: no limb is systematically relaxed first */
       int r=3*i; real v=vf[r]+bn[i]; for (int c=0;c<12;c++) v+=W[r][c]*lam[c];
       real ln=lam[r]-v/W[r][r]; if (ln<0) ln=0; lam[r]=ln;
       for (int k=1;k<3;k++) { int rr=r+k; real vt=vf[rr]; for (int c=0;c<12;c++) vt+=W[rr][c]*lam[c];
