@@ -18,6 +18,7 @@
 #include <math.h>
 #include <new>
 #include "lm_math.h"
+#include "lm_rng.h"
 #include "../../include/lm_engine.h"
 
 #define HUB_FLOATS 10
@@ -58,7 +59,7 @@ struct lm_engine {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-LM_DEV uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+LM_DEV uint32_t mix32(uint32_t x) { return lm_mix32(x); }
 LM_DEV void hash_uniform3(uint32_t seed, uint32_t env, uint32_t episode, float* u) {
   uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(episode * 0x85EBCA6BU + 0x165667B1U));
 #pragma unroll
@@ -86,9 +87,7 @@ LM_DEV float dr_sample(uint32_t seed, uint32_t stream, uint32_t env, uint32_t ke
   // components 2p and 2p+1 share one pair of uniforms (Box-Muller's cosine and sine branches): calls for neighbouring components
   // share the hashes, the logarithm, the square root and the sincos after common-subexpression elimination
   const uint32_t pair = idx >> 1; const bool odd = (idx & 1U) != 0;
-  uint32_t base = mix32(seed ^ mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ mix32(stream * 0x27D4EB2FU + 0x632BE5ABU));
-  uint32_t r1 = mix32(base + (2U * pair + 1U) * 0xC2B2AE35U), r2 = mix32(base + (2U * pair + 2U) * 0xC2B2AE35U);
-  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
+  float u1, u2; lm_rng_pair(lm_rng_base(seed, stream, env, key), pair, &u1, &u2);
   if (dist == LM_DR_GAUSSIAN) { float sn, cs; lm_sincos(6.283185307179586f * u2, &sn, &cs); return p0 + p1 * (sqrtf(-2.0f * logf(u1)) * (odd ? sn : cs)); }
   const float u = odd ? u1 - (1.0f / 16777216.0f) : u2;
   if (dist == LM_DR_UNIFORM) return p0 + (p1 - p0) * u;

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include "../../include/lm_policy.h"
 #include "../../include/lm_engine.h"
+#include "lm_rng.h"
 #include <new>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -53,15 +54,11 @@ __device__ __forceinline__ constexpr int edge_tgt(int e) { return e < 4 ? e + 1 
 __device__ __forceinline__ constexpr int joint_col(int n, int k) { return 16 + 12 * k + (n <= 4 ? n - 1 : (n <= 8 ? 4 + 2 * (n - 5) : 5 + 2 * (n - 9))); }
 
 // ---- counter-based standard normal for the fused action sampling (same generator as lm_engine.hip dr_sample, stream 9)
-__device__ __forceinline__ uint32_t ro_mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 __device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
   // actions 2p and 2p+1 are the cosine and sine branches of one Box-Muller pair
-  const uint32_t pair = idx >> 1; const bool odd = (idx & 1U) != 0;
-  uint32_t base = ro_mix32(seed ^ ro_mix32(env * 0x9E3779B9U + 0x7F4A7C15U) ^ ro_mix32(key * 0x85EBCA6BU + 0x165667B1U) ^ ro_mix32(9U * 0x27D4EB2FU + 0x632BE5ABU));
-  uint32_t r1 = ro_mix32(base + (2U * pair + 1U) * 0xC2B2AE35U), r2 = ro_mix32(base + (2U * pair + 2U) * 0xC2B2AE35U);
-  float u1 = ((float)(r1 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 8) * (1.0f / 16777216.0f);
+  float u1, u2; lm_rng_pair(lm_rng_base(seed, LM_RNG_STREAM_ACTION_SAMPLING, env, key), idx >> 1, &u1, &u2);
   float sn, cs; sincosf(6.283185307179586f * u2, &sn, &cs);
-  return sqrtf(-2.0f * logf(u1)) * (odd ? sn : cs);
+  return sqrtf(-2.0f * logf(u1)) * ((idx & 1U) ? sn : cs);
 }
 // (episode_count, progress_buf) identifies an env-step: progress restarts at every reset and the episode count moves on
 __device__ __forceinline__ uint32_t ro_key(const int64_t* __restrict__ cnt, int N, int env) {

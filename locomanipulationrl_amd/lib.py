@@ -105,7 +105,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     src = os.path.join(_CSRC, "lm_engine.hip")
     src2 = os.path.join(_CSRC, "lm_policy.hip")
     inc = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include")
-    deps = [src, src2, os.path.join(_CSRC, "lm_math.h"), os.path.join(inc, "lm_engine.h"), os.path.join(inc, "lm_policy.h")]
+    deps = [src, src2, os.path.join(_CSRC, "lm_math.h"), os.path.join(_CSRC, "lm_rng.h"), os.path.join(inc, "lm_engine.h"), os.path.join(inc, "lm_policy.h")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
