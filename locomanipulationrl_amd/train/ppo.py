@@ -50,7 +50,7 @@ class RunningStandardScaler:
 class PPO:
     def __init__(self, env, model, rollouts=48, learning_epochs=5, mini_batches=1, gamma=0.99, lam=0.95, lr=3e-4, kl_threshold=0.012,
                  grad_norm_clip=1.0, ratio_clip=0.2, value_clip=0.2, value_loss_scale=1.0, entropy_loss_scale=0.0, hip_inference=True,
-                 fused_rollout=True):
+                 fused_rollout=True, freeze_obs_scaler=False):
         self.env, self.model = env, model
         self.dev = next(model.parameters()).device
         self.N = env.num_envs
@@ -58,6 +58,7 @@ class PPO:
         self.gamma, self.lam, self.lr, self.kl_thr = gamma, lam, lr, kl_threshold
         self.gclip, self.rclip, self.vclip, self.vscale, self.escale = grad_norm_clip, ratio_clip, value_clip, value_loss_scale, entropy_loss_scale
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
+        self.freeze_obs_scaler = freeze_obs_scaler          # diagnostics: identity observation scaler (mean 0, var 1)
         self.n_obs = int(env.observation_space.shape[0])          # 88 for the custom-controller tasks
         self.obs_scaler = RunningStandardScaler(self.n_obs, self.dev); self.val_scaler = RunningStandardScaler(1, self.dev)
         # MFMA forward kernels: MLP on the 64- and 88-wide observations, GNN on the 64-wide one
@@ -121,7 +122,8 @@ class PPO:
         obs, act = self.b_obs.reshape(-1, self.n_obs), self.b_act.reshape(-1, 12)
         old_logp, old_val = self.b_logp.reshape(-1), self.b_val.reshape(-1)
         ret, adv = ret.reshape(-1), adv.reshape(-1)
-        self.obs_scaler.update(obs); self.val_scaler.update(ret.unsqueeze(-1))      # preprocessors train on the first epoch's data
+        if not self.freeze_obs_scaler: self.obs_scaler.update(obs)
+        self.val_scaler.update(ret.unsqueeze(-1))      # preprocessors train on the first epoch's data
         obs_n = self.obs_scaler(obs); ret_n = self.val_scaler(ret.unsqueeze(-1)).squeeze(-1); old_val_n = self.val_scaler(old_val.unsqueeze(-1)).squeeze(-1)
         n = obs.shape[0]; stats = {}
         for epoch in range(self.epochs):

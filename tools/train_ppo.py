@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--out", default=""); ap.add_argument("--log-every", type=int, default=5)
     ap.add_argument("--fixed-lr", action="store_true", help="no KL-adaptive learning rate (diagnostics; not the reference recipe)")
     ap.add_argument("--gnn-env-order", action="store_true", help="diagnostic: route GNN node k's output to the joint whose state node k reads (the reference feeds node order straight to the env)")
+    ap.add_argument("--no-obs-scaler", action="store_true", help="diagnostic: identity observation scaler")
     ap.add_argument("--no-hip", action="store_true", help="diagnostic: torch forward in the rollouts instead of the MFMA kernels")
     ap.add_argument("--no-fused", action="store_true", help="drive the rollout step by step from Python instead of the captured hipGraph")
     a = ap.parse_args()
@@ -38,7 +39,7 @@ def main():
         inv = inv.to(f"cuda:{local}"); _step = env.step
         env.step = lambda act: _step(act[:, inv].contiguous())
         a.no_fused = True
-    ppo = PPO(env, model, hip_inference=hip and not a.no_hip, fused_rollout=not a.no_fused, **({"kl_threshold": 0.0} if a.fixed_lr else {}))
+    ppo = PPO(env, model, hip_inference=hip and not a.no_hip, fused_rollout=not a.no_fused, **({"kl_threshold": 0.0} if a.fixed_lr else {}), freeze_obs_scaler=a.no_obs_scaler)
     hist = ppo.train(a.timesteps, log_every=a.log_every, log=(lambda r: print(json.dumps(r), flush=True)) if rank == 0 else (lambda r: None))
     if rank == 0 and a.out:
         json.dump({"task": a.task, "num_envs": a.num_envs, "world": world, "policy": a.policy, "history": hist}, open(a.out, "w"), indent=1)
