@@ -65,6 +65,23 @@ def test_standing_is_stable(robot_model):
     assert knees[:, :, 2].min() > 0.04 and np.abs(phys[:, 3:7] - [1, 0, 0, 0]).max() < 0.01
 
 
+def test_ground_reaction_balances_weight(robot_model):
+    """Static equilibrium: the normal impulses the contact solver finds for a settled robot add up to m g dt (and the plate's weight is
+    carried by the four tips in the manipulation scene) - a known answer for the contact model that needs no PhysX."""
+    import ctypes as C
+    for ep, total in ((loco_params(), float(np.sum(robot_model.mass))), (mani_params(), mani_params().plate_mass)):
+        o = Oracle(robot_model, ep)
+        phys, task, cnt = o.new_state(1); o.reset(phys, task, cnt)
+        for _ in range(400):
+            o.substep(phys, np.zeros((1, 12)))
+        W = np.zeros((12, 12)); vf = np.zeros(12); bn = np.zeros(4); lam = np.zeros(12)
+        o.lib.lmo_contact_problem(C.byref(o.model), C.byref(o.params), o._p(phys[0]), o._p(np.zeros(12)), o._p(W), o._p(vf), o._p(bn), o._p(lam))
+        fn = lam[0::3].sum() / ep.dt
+        assert abs(fn - total * ep.gravity) < 0.03 * total * ep.gravity, (fn, total * ep.gravity)
+        assert (lam[0::3] > 0).all()                                                    # all four tips carry load
+        assert np.abs(lam[1::3]).max() <= ep.mu * lam[0::3].max() + 1e-12              # friction inside the pyramid
+
+
 def test_plate_rests_on_inverted_robot(robot_model):
     ep = mani_params(); o = Oracle(robot_model, ep)
     phys, task, cnt = o.new_state(2); o.reset(phys, task, cnt)
