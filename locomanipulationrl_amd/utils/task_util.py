@@ -19,6 +19,7 @@ def task_map():
         "JointLocomanipulationVertical": JointLocomanipulationVertical,
         "QuadrupedPoseControlCustomController": QuadrupedPoseControlCustomController,
         "QuadrupedManipulatePlateCustomController": QuadrupedManipulatePlateCustomController,
+        "QuadrupedPoseControlCustomControllerDR": QuadrupedPoseControlCustomController,      # same task, the DR YAML (its ..._dr.py adds record / replay only)
         "QuadrupedPoseControlPositionControl": QuadrupedPoseControlPositionControl,
         "QuadrupedManipulatePlatePositionControl": QuadrupedManipulatePlatePositionControl,
         "JointLocomanipulationPositionControl": JointLocomanipulationPositionControl,
