@@ -48,9 +48,24 @@ def cpu_baseline(steps: int = 150, envs: int = 4096):
     for t in range(steps):
         o.step(phys, task, cnt, acts[2 + t], seed=42)
     dt = time.perf_counter() - t0
-    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{envs} envs x {steps} steps of the same task on the CPU oracle (fp32 build, OpenMP over envs, {dt:.1f} s); "
-                      "PhysX-CPU itself is unavailable (closed source, not installed)"}
+    out = {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{envs} envs x {steps} steps of the same task on the CPU oracle (fp32 build, OpenMP over envs, {dt:.1f} s); "
+                     "PhysX-CPU itself is unavailable (closed source, not installed)"}
+    try:      # the same oracle on ONE core (SURVEY 8d asks for both)
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        n1, s1 = 1024, 12
+        p1, t1, c1 = o.new_state(n1)
+        o.step(p1, t1, c1, acts[0][:n1], seed=42)
+        t0 = time.perf_counter()
+        for t in range(s1):
+            o.step(p1, t1, c1, acts[(2 + t) % len(acts)][:n1], seed=42)
+        d1 = time.perf_counter() - t0
+        out["value_1core"] = n1 * s1 / d1
+        out["sample"] += f"; one core: {n1} envs x {s1} steps ({d1:.1f} s)"
+    except OSError:
+        pass
+    return out
 
 
 def main():
