@@ -45,7 +45,7 @@ static int fail(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s"
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", #x, hipGetErrorString(e_)); return LM_EHIP; } } while (0)
 
 struct lm_engine {
-  int N, n_tasks, split, nblocks, num_obs;
+  int N, n_tasks, split, nblocks, num_obs, device;
   uint32_t seed;
   lm_params* d_params;     // [2]
   float* d_table;
@@ -1269,9 +1269,12 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
         return fail(LM_EINVAL, "lm_create: invalid domain-randomisation channel (operation / distribution / interval / parameters)");
     }
   }
+  int device = 0;
+  HIPCHK(hipGetDevice(&device));
   lm_engine* h = new (std::nothrow) lm_engine();
   if (!h) return fail(LM_ENOMEM, "lm_create: host allocation failed");
   memset(h, 0, sizeof(*h));
+  h->device = device;          // every buffer lives on the device current at creation; launches check it (on_device)
   h->N = n_envs; h->n_tasks = n_tasks; h->split = (n_tasks == 2) ? split_env : n_envs; h->seed = seed;
   h->nblocks = (n_envs + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE;
   h->num_obs = params[0].num_obs; h->dr_enabled = params[0].dr_enabled != 0;
@@ -1294,8 +1297,10 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_acc, 16 * sizeof(long long));
   ALLOC(h->d_stats, 64);
 #undef ALLOC
-  HIPCHK(hipMemcpy(h->d_params, h->h_params, 2 * sizeof(lm_params), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->d_table, table, LM_TABLE_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+  if (hipMemcpy(h->d_params, h->h_params, 2 * sizeof(lm_params), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_table, table, LM_TABLE_FLOATS * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    lm_destroy(h); return fail(LM_EHIP, "lm_create: parameter / table upload failed");
+  }
   // identity quaternions so that an un-reset state is still valid; reset_buf = 1 (rl_task.py:111)
   {
     float* tmp = new float[LM_STATE_ROWS * N](); int64_t* ct = new int64_t[LM_CNT_ROWS * N]();
@@ -1317,6 +1322,14 @@ int lm_destroy(lm_engine* h) {
   return LM_OK;
 }
 
+// The engine's buffers belong to the device that was current in lm_create: a launch from a thread whose current
+// device differs would run on the wrong GPU (multi-GPU hosts run one process per GPU, so this is a caller bug).
+static bool on_device(const lm_engine* h) {
+  int d = -1;
+  return hipGetDevice(&d) == hipSuccess && d == h->device;
+}
+#define CHECK_DEVICE(h, fn) do { if (!on_device(h)) return fail(LM_EINVAL, fn ": the calling thread's current device is not the engine's device"); } while (0)
+
 static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states, float* out_rew, int64_t* out_resets) {
   StepArgs A;
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
@@ -1330,6 +1343,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states, float* out_rew,
             int64_t* out_resets, float* out_extras, void* stream) {
   if (!h || !actions) return fail(LM_EINVAL, "lm_step: null handle or actions");
+  CHECK_DEVICE(h, "lm_step");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   if (h->dr_enabled) hipLaunchKernelGGL(k_step_dr, dim3(h->nblocks), dim3(64), 0, s, A);
@@ -1341,6 +1355,7 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
 int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* out_states, float* out_rew,
                     int64_t* out_resets, float* out_extras, void* stream) {
   if (!h || !actions) return fail(LM_EINVAL, "lm_post_physics: null handle or actions");
+  CHECK_DEVICE(h, "lm_post_physics");
   if (h->dr_enabled) return fail(LM_EINVAL, "lm_post_physics: a randomised engine runs through lm_step only");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
@@ -1352,6 +1367,7 @@ int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* o
 
 int lm_reset_all(lm_engine* h, void* stream) {
   if (!h) return fail(LM_EINVAL, "lm_reset_all: null handle");
+  CHECK_DEVICE(h, "lm_reset_all");
   hipLaunchKernelGGL(k_reset_all, dim3((h->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->d_cnt, h->N);
   HIPCHK(hipGetLastError());
   return LM_OK;
@@ -1360,6 +1376,7 @@ int lm_reset_all(lm_engine* h, void* stream) {
 int lm_task_eval(lm_engine* h, const float* readback, const float* actions, float* out_obs, float* out_states, float* out_rew,
                  int64_t* out_resets, float* out_extras, void* stream) {
   if (!h || !readback || !actions) return fail(LM_EINVAL, "lm_task_eval: null argument");
+  CHECK_DEVICE(h, "lm_task_eval");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   hipLaunchKernelGGL(k_task_eval, dim3(h->nblocks), dim3(64), 0, s, A, readback);
@@ -1369,6 +1386,7 @@ int lm_task_eval(lm_engine* h, const float* readback, const float* actions, floa
 
 int lm_apply_resets(lm_engine* h, const float* goal_rand, void* stream) {
   if (!h) return fail(LM_EINVAL, "lm_apply_resets: null handle");
+  CHECK_DEVICE(h, "lm_apply_resets");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, nullptr, goal_rand, nullptr, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_apply_resets, dim3(h->nblocks), dim3(64), 0, s, A);
@@ -1379,6 +1397,7 @@ int lm_apply_resets(lm_engine* h, const float* goal_rand, void* stream) {
 
 int lm_substeps(lm_engine* h, const float* targets, int n, void* stream) {
   if (!h || !targets || n < 0) return fail(LM_EINVAL, "lm_substeps: bad argument");
+  CHECK_DEVICE(h, "lm_substeps");
   StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_substeps, dim3(h->nblocks), dim3(64), 0, (hipStream_t)stream, A, targets, n);
   HIPCHK(hipGetLastError());
@@ -1387,6 +1406,7 @@ int lm_substeps(lm_engine* h, const float* targets, int n, void* stream) {
 
 int lm_forward_kinematics(lm_engine* h, float* tips, float* knees, void* stream) {
   if (!h || !tips || !knees) return fail(LM_EINVAL, "lm_forward_kinematics: null argument");
+  CHECK_DEVICE(h, "lm_forward_kinematics");
   StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_fk, dim3(h->nblocks), dim3(64), 0, (hipStream_t)stream, A, tips, knees);
   HIPCHK(hipGetLastError());
@@ -1395,6 +1415,7 @@ int lm_forward_kinematics(lm_engine* h, float* tips, float* knees, void* stream)
 
 int lm_debug_dynamics(lm_engine* h, float* M, float* hvec, void* stream) {
   if (!h || !M || !hvec) return fail(LM_EINVAL, "lm_debug_dynamics: null argument");
+  CHECK_DEVICE(h, "lm_debug_dynamics");
   if (h->h_params[0].mode != LM_MODE_LOCO || h->n_tasks != 1) return fail(LM_EINVAL, "lm_debug_dynamics: loco engines only");
   StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_debug_dyn, dim3(h->nblocks), dim3(64), 0, (hipStream_t)stream, A, M, hvec);

@@ -182,6 +182,10 @@ class Engine:
             raise EngineError("no HIP device visible: the engine runs on MI355X only (no CPU fallback)")
         self.torch = torch
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise EngineError(f"the engine runs on a HIP device, not {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = load_library()
         self.num_envs = int(num_envs)
         params = list(params)
@@ -231,8 +235,8 @@ class Engine:
         return None if t is None else C.c_void_p(t.data_ptr())
 
     def _f32(self, t, shape):
-        assert t.is_cuda and t.dtype == self.torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape), \
-            (t.device, t.dtype, tuple(t.shape), shape)
+        assert t.device == self.device and t.dtype == self.torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape), \
+            (t.device, self.device, t.dtype, tuple(t.shape), shape)
         return t
 
     # ------------------------------------------------------------------ C-ABI calls
@@ -246,7 +250,7 @@ class Engine:
         if out_rew is not None: self._f32(out_rew, (N,))
         if out_extras is not None: self._f32(out_extras, (NUM_EXTRAS,))
         if out_resets is not None:
-            assert out_resets.dtype == self.torch.int64 and tuple(out_resets.shape) == (N,) and out_resets.is_cuda
+            assert out_resets.dtype == self.torch.int64 and tuple(out_resets.shape) == (N,) and out_resets.device == self.device and out_resets.is_contiguous()
         self._check(self.lib.lm_step(self._h, self._p(actions), self._p(goal_rand), self._p(out_obs), self._p(out_states),
                                      self._p(out_rew), self._p(out_resets), self._p(out_extras), self._stream()))
 

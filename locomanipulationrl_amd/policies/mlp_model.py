@@ -65,11 +65,12 @@ def mlp_forward_hip(obs: torch.Tensor, packed: torch.Tensor):
     from ..lib import load_library
     lib = load_library()
     assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] in (64, 88)
-    assert packed.is_cuda and packed.numel() == lib.lm_mlp_param_count_obs(obs.shape[1])
+    assert packed.device == obs.device and packed.dtype == torch.float32 and packed.is_contiguous() and packed.numel() == lib.lm_mlp_param_count_obs(obs.shape[1])
     B = obs.shape[0]
     mean = torch.empty((B, 12), device=obs.device); value = torch.empty((B, 1), device=obs.device)
-    rc = lib.lm_mlp_forward_obs(C.c_void_p(obs.data_ptr()), B, obs.shape[1], C.c_void_p(packed.data_ptr()), C.c_void_p(mean.data_ptr()),
-                            C.c_void_p(value.data_ptr()), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+    with torch.cuda.device(obs.device):            # the kernel launches on the calling thread's current device
+        rc = lib.lm_mlp_forward_obs(C.c_void_p(obs.data_ptr()), B, obs.shape[1], C.c_void_p(packed.data_ptr()), C.c_void_p(mean.data_ptr()),
+                                C.c_void_p(value.data_ptr()), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"lm_mlp_forward failed ({rc})")
     return mean, value
