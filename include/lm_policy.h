@@ -59,7 +59,13 @@ int lm_sample_actions(const float* mean, const float* log_std, const int64_t* cn
 int lm_rollout_create(lm_rollout** out, struct lm_engine* env, int policy, const float* policy_params, const float* log_std, int T,
                       uint32_t noise_seed, float* obs, float* actions, float* logp, float* values, float* rewards, int64_t* dones,
                       float* extras);
-/* Enqueue the rollout on `stream`: use_graph != 0 replays a hipGraph captured on first use (one launch), 0 enqueues the 4T+1 kernels. */
+/* Enqueue the rollout on `stream`.  use_graph: LM_ROLLOUT_ENQUEUE enqueues the 2T+1 kernels, LM_ROLLOUT_GRAPH replays a hipGraph of them
+ * captured on first use (one launch), LM_ROLLOUT_PERSISTENT runs the whole rollout inside ONE kernel (every block keeps its 16 envs for
+ * the T steps, the observations go from the step to the next forward through LDS; un-randomised engines only, -1 otherwise).
+ * The three modes write bit-identical buffers. */
+#define LM_ROLLOUT_ENQUEUE 0
+#define LM_ROLLOUT_GRAPH 1
+#define LM_ROLLOUT_PERSISTENT 2
 int lm_rollout_run(lm_rollout* r, int use_graph, void* stream);
 int lm_rollout_destroy(lm_rollout* r);
 

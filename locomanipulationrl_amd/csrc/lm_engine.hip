@@ -20,6 +20,9 @@
 #include "lm_math.h"
 #include "lm_rng.h"
 #include "../../include/lm_engine.h"
+#include "../../include/lm_policy.h"
+#include "lm_policy_dev.h"
+#include "lm_internal.h"
 
 #define HUB_FLOATS 10
 #define LIMB_STRIDE 119
@@ -644,13 +647,34 @@ LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
 
 struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms; float *out_obs, *out_states, *out_rew; int64_t* out_resets;
                  long long* acc;          // int64 [16]: fixed-point sums of the 12 per-env terms, first-task shares of goal_reset / reset, -, arrival ticket
-                 char* stats; float* extras; float* out_extras; int split_block; };
+                 char* stats; float* extras; float* out_extras; int split_block;
+                 int defer_finalize; };   // 1: only accumulate; the extras of this step are published later (persistent rollout kernel)
 #define ACC_SCALE 1048576.0f      // 2^20: integer accumulation makes the means independent of the arrival order (bitwise reproducible)
 
 LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
   int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
   if (num_rst > max_cnt) { sr = (float)num_succ / (float)num_rst; num_rst = 0; num_succ = 0; }
   ns[0] = num_succ + add_succ; ns[1] = num_rst + add_rst; *rate = sr;
+}
+
+// Totals of one step -> extras (means of the reward terms, success-rate windows); clears the accumulators.  One wavefront.
+LM_DEV void finalize_extras(const lm_params* __restrict__ P, const OutPtrs& W, int N, int lane) {
+  long long tot = 0;
+  if (lane < 14) tot = __hip_atomic_load(W.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
+  if (lane < 7) { float m = sum / (float)N; W.extras[lane] = m; if (W.out_extras) W.out_extras[lane] = m; }
+  if (lane >= 9 && lane < 12) { float m = sum / (float)N; W.extras[lane + 1] = m; if (W.out_extras) W.out_extras[lane + 1] = m; }      // extras 10..12
+  const float gsf = __shfl(sum, 7), rsf = __shfl(sum, 8), glf = __shfl(sum, 12), rlf = __shfl(sum, 13);
+  if (lane == 0) {
+    int64_t* ns = reinterpret_cast<int64_t*>(W.stats); float* rate = reinterpret_cast<float*>(W.stats + 48);
+    const int64_t gs = (int64_t)(gsf + 0.5f), rs = (int64_t)(rsf + 0.5f), gl = (int64_t)(glf + 0.5f), rl = (int64_t)(rlf + 0.5f);
+    success_window(ns + 0, rate + 0, gs, rs, (int64_t)P->max_reset_counts);
+    success_window(ns + 2, rate + 1, gl, rl, (int64_t)P->max_reset_counts);
+    success_window(ns + 4, rate + 2, gs - gl, rs - rl, (int64_t)P->max_reset_counts);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { W.extras[7 + k] = rate[k]; if (W.out_extras) W.out_extras[7 + k] = rate[k]; }
+  }
+  if (lane < 16) __hip_atomic_store(W.acc + lane, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct DrOut { int64_t* drc; uint32_t seed, dr_step; int64_t rand_buf, reset_key; uint32_t* sKey; };      // sKey: LDS [16][2] {corr key, fire}
@@ -738,30 +762,15 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
 #pragma unroll
     for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
   }
-  {
+  if (!W.defer_finalize) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's atomics (and its stores) have been performed
     asm volatile("" :: "v"(dummy));
     int ticket = 0;
     if (lane == 0) ticket = (int)__hip_atomic_fetch_add(W.acc + 15, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0);
-    if (ticket == (int)gridDim.x - 1) {
-      long long tot = 0;
-      if (lane < 14) tot = __hip_atomic_load(W.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
-      if (lane < 7) { float m = sum / (float)N; W.extras[lane] = m; if (W.out_extras) W.out_extras[lane] = m; }
-      if (lane >= 9 && lane < 12) { float m = sum / (float)N; W.extras[lane + 1] = m; if (W.out_extras) W.out_extras[lane + 1] = m; }      // extras 10..12
-      const float gsf = __shfl(sum, 7), rsf = __shfl(sum, 8), glf = __shfl(sum, 12), rlf = __shfl(sum, 13);
-      if (lane == 0) {
-        int64_t* ns = reinterpret_cast<int64_t*>(W.stats); float* rate = reinterpret_cast<float*>(W.stats + 48);
-        const int64_t gs = (int64_t)(gsf + 0.5f), rs = (int64_t)(rsf + 0.5f), gl = (int64_t)(glf + 0.5f), rl = (int64_t)(rlf + 0.5f);
-        success_window(ns + 0, rate + 0, gs, rs, (int64_t)P->max_reset_counts);
-        success_window(ns + 2, rate + 1, gl, rl, (int64_t)P->max_reset_counts);
-        success_window(ns + 4, rate + 2, gs - gl, rs - rl, (int64_t)P->max_reset_counts);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { W.extras[7 + k] = rate[k]; if (W.out_extras) W.out_extras[7 + k] = rate[k]; }
-      }
-      if (lane < 16) __hip_atomic_store(W.acc + lane, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (ticket == (int)gridDim.x - 1) finalize_extras(P, W, N, lane);
+  } else {
+    asm volatile("" :: "v"(dummy));
   }
 }
 
@@ -1024,6 +1033,74 @@ __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
   else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 1>(A, P, sTab, sObs, sSt, sStash); }
 }
 
+
+// ---- persistent rollout: T x (policy forward -> action sampling -> physics step) + the bootstrap forward without leaving
+// the kernel.  A block owns its 16 envs for the whole rollout: wavefront 0 runs the step exactly as k_step does (same step_body), the
+// observations it stages in LDS feed the next forward directly, and all four wavefronts run the policy tile (MLP or GNN, lm_policy_dev.h).  Blocks
+// never wait for each other, so a step costs a block its own time rather than the slowest block's, and no launch boundary is paid.
+// The per-step reductions go to per-step accumulators (blocks drift apart); k_rollout_finalize publishes the extras afterwards, in
+// step order, with the same arithmetic as the last-arriver path of write_outputs.
+struct RolloutDev {
+  const float* params; const float* log_std;
+  float *obs, *actions, *logp, *values, *rewards; int64_t* dones;
+  long long* acc_steps; int T; uint32_t noise_seed;
+};
+
+// the step of the persistent kernel as a real call: its ~350 registers are then allocated separately from the policy tile's
+LM_DEV void step_dispatch(const StepArgs& B, const lm_params* P, float* sTab, float* sObs, float* sSt, float4* sStash) {
+  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(B, P, sTab, sObs, sSt, sStash); }
+  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0>(B, P, sTab, sObs, sSt, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 0>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(B, P, sTab, sObs, sSt, sStash); }
+}
+
+template <int NOBS, int POLICY> struct PolicySmem { MlpSmem<NOBS> M; };
+template <int NOBS> struct PolicySmem<NOBS, LM_POLICY_GNN> { GnnSmem M; };
+
+template <int NOBS, int POLICY>
+__global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
+  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
+  __shared__ float4 sStash[STASH_SLOTS * 64];
+  __shared__ PolicySmem<NOBS, POLICY> PS;
+  const int t = threadIdx.x, env0 = blockIdx.x * ENVS_PER_WAVE;
+  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+  for (int k = 0; k <= R.T; k++) {
+    // The loop body must be compiled like a stand-alone kernel: without these opaque copies the compiler hoists every loop-invariant
+    // address (one 64-bit pointer per state row and per weight chunk) out of the loop and spills hundreds of registers to scratch.
+    int z = 0; asm volatile("" : "+s"(z));      // an opaque zero, new in every iteration
+    StepArgs B = A; B.state = A.state + z; B.cnt = A.cnt + z; B.N = A.N + z;
+    const float* Wk = R.params + z; const lm_params* Pk = P + z;
+    const size_t Nk = (size_t)B.N;
+    SampleArgs SA{};
+    if (k < R.T) { SA.log_std = R.log_std; SA.cnt = B.cnt; SA.seed = R.noise_seed; SA.actions = R.actions + (size_t)k * Nk * 12; SA.logp = R.logp + (size_t)k * Nk; }
+    if (POLICY == LM_POLICY_GNN) {
+      if (k == 0) gnn_block<false>(R.obs, 0.f, B.N, env0, Wk, nullptr, R.values, SA, reinterpret_cast<GnnSmem&>(PS.M), t);
+      else gnn_block<true>(sObs, Pk->clip_obs, B.N, env0, Wk, nullptr, R.values + (size_t)k * Nk, SA, reinterpret_cast<GnnSmem&>(PS.M), t);
+    } else {
+      if (k == 0) mlp_block<NOBS, false>(R.obs, 0.f, B.N, env0, Wk, nullptr, R.values, SA, reinterpret_cast<MlpSmem<NOBS>&>(PS.M), t);
+      else mlp_block<NOBS, true>(sObs, Pk->clip_obs, B.N, env0, Wk, nullptr, R.values + (size_t)k * Nk, SA, reinterpret_cast<MlpSmem<NOBS>&>(PS.M), t);
+    }
+    if (k == R.T) break;
+    if (t < 64) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the sampled actions are in memory before the step reads them back
+      B.actions = SA.actions; B.goal_rand = nullptr;
+      B.W.out_obs = R.obs + (size_t)(k + 1) * Nk * NOBS; B.W.out_states = nullptr; B.W.out_rew = R.rewards + (size_t)k * Nk;
+      B.W.out_resets = R.dones + (size_t)k * Nk; B.W.out_extras = nullptr; B.W.acc = R.acc_steps + 16 * k; B.W.defer_finalize = 1;
+      step_dispatch(B, Pk, sTab, sObs, sSt, sStash);
+    }
+    __syncthreads();        // the step's stores (state, counters, observations) are performed before anyone goes on
+  }
+}
+
+__global__ void __launch_bounds__(64) k_rollout_finalize(const lm_params* params, OutPtrs W, int N, long long* acc_steps, float* extras, int T) {
+  for (int k = 0; k < T; k++) {
+    W.acc = acc_steps + 16 * k; W.out_extras = extras ? extras + (size_t)k * LM_NUM_EXTRAS : nullptr;
+    finalize_extras(params, W, N, threadIdx.x);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // the window counters of step k are in memory before step k + 1 reads them
+  }
+}
+
 __global__ void __launch_bounds__(64) k_reset_all(int64_t* cnt, int N) {
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i < N) cnt[3 * (size_t)N + i] = 1;
@@ -1240,6 +1317,7 @@ static void derive_params(lm_params* p) {
   p->acc_dt_inv = (float)(1.0 / ((double)p->dt * (double)(p->acc_substeps > 0 ? p->acc_substeps : 1)));
 }
 
+
 extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
@@ -1334,7 +1412,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   StepArgs A;
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
   A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.acc = h->d_acc;
-  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE;
+  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE; A.W.defer_finalize = 0;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
   A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
   return A;
@@ -1444,3 +1522,20 @@ int lm_num_obs(const lm_engine* h) { return h ? h->num_obs : 0; }
 int lm_set_seed(lm_engine* h, uint32_t seed) { if (!h) return fail(LM_EINVAL, "lm_set_seed: null handle"); h->seed = seed; return LM_OK; }
 
 }  // extern "C"
+
+// (lm_internal.h) the persistent rollout launch used by lm_rollout_run (lm_policy.hip)
+int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStream_t s) {
+  if (!h || !R.params || !R.log_std || !R.obs || !R.actions || !R.logp || !R.values || !R.rewards || !R.dones || !R.acc_steps || R.T <= 0) return -1;
+  if (h->dr_enabled || R.nobs != h->num_obs) return -1;
+  if (!on_device(h)) return -1;
+  StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  RolloutDev D; D.params = R.params; D.log_std = R.log_std; D.obs = R.obs; D.actions = R.actions; D.logp = R.logp; D.values = R.values;
+  D.rewards = R.rewards; D.dones = R.dones; D.acc_steps = R.acc_steps; D.T = R.T; D.noise_seed = R.noise_seed;
+  if (policy == LM_POLICY_MLP && R.nobs == 64) hipLaunchKernelGGL((k_rollout<64, LM_POLICY_MLP>), dim3(h->nblocks), dim3(256), 0, s, A, D);
+  else if (policy == LM_POLICY_MLP && R.nobs == LM_MAX_OBS) hipLaunchKernelGGL((k_rollout<LM_MAX_OBS, LM_POLICY_MLP>), dim3(h->nblocks), dim3(256), 0, s, A, D);
+  else if (policy == LM_POLICY_GNN && R.nobs == 64) hipLaunchKernelGGL((k_rollout<64, LM_POLICY_GNN>), dim3(h->nblocks), dim3(256), 0, s, A, D);
+  else return -1;
+  hipLaunchKernelGGL(k_rollout_finalize, dim3(1), dim3(64), 0, s, h->d_params, A.W, h->N, R.acc_steps, R.extras, R.T);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+

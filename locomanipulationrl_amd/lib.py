@@ -372,8 +372,13 @@ class Rollout:
         if rc != 0:
             raise EngineError(f"lm_rollout_create failed ({rc})")
 
-    def run(self, use_graph: bool = True):
-        rc = self.engine.lib.lm_rollout_run(self._h, 1 if use_graph else 0, self.engine._stream())
+    MODES = {"enqueue": 0, "graph": 1, "persistent": 2}
+
+    def run(self, use_graph=True):
+        """use_graph: False / "enqueue" (2T+1 launches), True / "graph" (one hipGraph replay) or "persistent" (the whole rollout in one kernel:
+        MLP policy on an un-randomised engine); identical buffers in all three modes."""
+        mode = self.MODES[use_graph] if isinstance(use_graph, str) else (1 if use_graph else 0)
+        rc = self.engine.lib.lm_rollout_run(self._h, mode, self.engine._stream())
         if rc != 0:
             raise EngineError(f"lm_rollout_run failed ({rc}): {self.engine.lib.lm_last_error().decode()}")
 

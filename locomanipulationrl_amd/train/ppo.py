@@ -77,6 +77,8 @@ class PPO:
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
             self.rollout = env._task.make_rollout(kind, self._packed, self._log_std, self.T, noise_seed=1000 + rank)
             ro = self.rollout
+            # one persistent kernel per rollout where the engine supports it (no domain randomisation), else the hipGraph replay
+            self._ro_mode = "graph" if env._task._dr_randomizer.randomize else "persistent"
             self.b_obs, self.b_act, self.b_logp, self.b_rew = ro.obs[:self.T], ro.actions, ro.logp, ro.rewards
 
     # ------------------------------------------------------------------ policy evaluation
@@ -101,7 +103,7 @@ class PPO:
             self.model.refresh(self.dev, self.obs_scaler.mean.float(), self.obs_scaler.var.float(), self.obs_scaler.eps, self.obs_scaler.clip)
             self._packed.copy_(self.model._packed); self._log_std.copy_(self.model.log_std_parameter.detach())
             ro.obs[0].copy_(obs_raw)
-            ro.run(use_graph=True)
+            ro.run(self._ro_mode)
             v = self.val_scaler(ro.values.reshape(-1, 1), inverse=True).reshape(self.T + 1, self.N)
             self.b_val, self.b_done = v[:self.T], ro.dones.float()
             return ro.obs[self.T], v[self.T], self.env._task.extras_dict(ro.extras[self.T - 1])

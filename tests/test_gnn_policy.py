@@ -225,3 +225,48 @@ def test_fused_rollout_on_a_custom_controller_task():
     eps = (ro.actions[3] - mu) / log_std.exp()
     assert abs(float(eps.mean())) < 0.1 and abs(float(eps.std()) - 1.0) < 0.1
     ro.close(); env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task_name,N,policy", [("QuadrupedPoseControl", 512, "mlp"), ("QuadrupedPoseControl", 500, "mlp"), ("QuadrupedManipulatePlate", 256, "mlp"),
+                                                ("JointLocomanipulation", 512, "mlp"), ("QuadrupedPoseControlCustomController", 256, "mlp"),
+                                                ("JointLocomanipulationPositionControl", 256, "mlp"),
+                                                ("JointLocomanipulationVertical", 512, "gnn"), ("QuadrupedPoseControl", 500, "gnn")])
+def test_persistent_rollout_kernel_equals_graph_replay(task_name, N, policy):
+    """SURVEY 8 f-2, one-kernel form: every block keeps its 16 envs for the T steps (wavefront 0 steps them exactly like k_step, all four
+    wavefronts run the policy tile -- MLP or GNN -- on the observations left in LDS) and the extras are published afterwards from per-step accumulators.  All
+    rollout buffers, the extras, the simulator state, the counters and the success windows must equal the hipGraph replay bit for bit;
+    two consecutive rollouts, so that the accumulators are checked to come back clean."""
+    from locomanipulationrl_amd.lib import Engine, Rollout, POLICY_GNN, POLICY_MLP
+    from locomanipulationrl_amd.model.robot_model import load_model
+    from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params
+    from locomanipulationrl_amd.utils.config import SimConfig, load_config
+    from locomanipulationrl_amd.utils.task_util import task_map
+    torch.manual_seed(5)
+    T = 20
+    task = task_map()[task_name](name=task_name, sim_config=SimConfig(load_config(task_name, num_envs=N)), env=None)
+    nobs = task.engine_params()[0].num_obs
+    if policy == "mlp":
+        model = SharedMLP(num_observations=nobs).cuda(); packed = pack_mlp_params(model, None, None).cuda(); kind = POLICY_MLP
+    else:
+        model = GraphPolicy().cuda(); packed = pack_gnn_params(model.net, model.mean_layer, model.value_layer).cuda(); kind = POLICY_GNN
+    log_std = torch.full((12,), -0.3, device="cuda")          # large noise: resets, saturation and goal changes inside the window
+    engs, ros = [], []
+    for _ in range(2):
+        e = Engine(load_model(task.model_asset), task.engine_params(), N, split_env=task.split_env(), seed=9)
+        o0 = torch.empty(N, nobs, device="cuda"); e.step(torch.zeros(N, 12, device="cuda"), None, o0)
+        r = Rollout(e, kind, packed, log_std, T, noise_seed=21); r.obs[0] = o0
+        engs.append(e); ros.append(r)
+    for rep in range(2):
+        ros[0].run("graph"); ros[1].run("persistent"); torch.cuda.synchronize()
+        for name in ("obs", "actions", "logp", "values", "rewards", "dones", "extras"):
+            a, b = getattr(ros[0], name), getattr(ros[1], name)
+            assert torch.equal(a, b), (task_name, policy, rep, name, float((a.float() - b.float()).abs().max()))
+        assert torch.equal(engs[0].state, engs[1].state) and torch.equal(engs[0].cnt, engs[1].cnt)
+        assert torch.equal(engs[0].stats_i64, engs[1].stats_i64) and torch.equal(engs[0].extras_buf, engs[1].extras_buf)
+        assert torch.equal(engs[0].obs_buf, engs[1].obs_buf) and torch.equal(engs[0].rew_buf, engs[1].rew_buf)
+        for r in ros: r.obs[0].copy_(r.obs[T])
+    assert int(ros[0].dones.sum()) > 0                        # episodes did end inside the window
+    for r in ros: r.close()
+    for e in engs: e.close()
