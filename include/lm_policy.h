@@ -62,10 +62,13 @@ int lm_rollout_create(lm_rollout** out, struct lm_engine* env, int policy, const
 /* Enqueue the rollout on `stream`.  use_graph: LM_ROLLOUT_ENQUEUE enqueues the 2T+1 kernels, LM_ROLLOUT_GRAPH replays a hipGraph of them
  * captured on first use (one launch), LM_ROLLOUT_PERSISTENT runs the whole rollout inside ONE kernel (every block keeps its 16 envs for
  * the T steps, the observations go from the step to the next forward through LDS; un-randomised engines only, -1 otherwise).
- * The three modes write bit-identical buffers. */
+ * A persistent block occupies a whole compute unit, so the mode pays up to 16 x (compute units) envs = 4096 on MI355X and serialises beyond;
+ * LM_ROLLOUT_AUTO picks it within that size on engines that support it and the graph otherwise.
+ * All modes write bit-identical buffers. */
 #define LM_ROLLOUT_ENQUEUE 0
 #define LM_ROLLOUT_GRAPH 1
 #define LM_ROLLOUT_PERSISTENT 2
+#define LM_ROLLOUT_AUTO 3
 int lm_rollout_run(lm_rollout* r, int use_graph, void* stream);
 int lm_rollout_destroy(lm_rollout* r);
 

@@ -1539,3 +1539,7 @@ int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStr
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs) {
+  if (!h || h->dr_enabled || nobs != h->num_obs) return 0;
+  return (policy == LM_POLICY_MLP && (nobs == 64 || nobs == LM_MAX_OBS)) || (policy == LM_POLICY_GNN && nobs == 64);
+}

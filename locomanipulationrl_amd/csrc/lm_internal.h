@@ -16,3 +16,5 @@ struct LmRolloutArgs {
 // T x (policy forward -> sampling -> step) + the bootstrap forward in ONE kernel launch (lm_engine.hip); policy = LM_POLICY_MLP / _GNN.
 // Returns 0, or a negative code when the engine cannot run it (domain-randomised engines; the GNN on 88-wide observations).
 int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStream_t s);
+// 1 when lm_internal_rollout can run this engine / policy / observation width
+int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs);

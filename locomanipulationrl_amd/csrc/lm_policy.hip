@@ -89,6 +89,7 @@ struct lm_rollout {
   lm_engine* env; int policy, T, N, nobs; uint32_t seed;
   const float *params, *log_std; float *obs, *actions, *logp, *values, *rewards, *extras; int64_t* dones;
   float* mean_tmp; const int64_t* cnt; long long* acc_steps;      // acc_steps: [T][16] accumulators of the persistent kernel
+  int n_cu; bool persistent_ok;                                   // compute units of the device; engine can run the persistent kernel
   hipGraphExec_t exec; hipStream_t exec_stream;
 };
 
@@ -132,6 +133,8 @@ int lm_rollout_create(lm_rollout** out, lm_engine* env, int policy, const float*
   r->cnt = (const int64_t*)lm_ptr(env, LM_PTR_CNT);
   if (hipMalloc((void**)&r->mean_tmp, (size_t)r->N * 12 * sizeof(float)) != hipSuccess) { delete r; return -2; }
   r->acc_steps = nullptr;
+  { int dev = 0, cus = 0; r->n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? cus : 0; }
+  r->persistent_ok = lm_internal_rollout_supported(env, policy, nobs) != 0;
   if (hipMalloc((void**)&r->acc_steps, (size_t)T * 16 * sizeof(long long)) != hipSuccess ||
       hipMemset(r->acc_steps, 0, (size_t)T * 16 * sizeof(long long)) != hipSuccess) { (void)hipFree(r->mean_tmp); if (r->acc_steps) (void)hipFree(r->acc_steps); delete r; return -2; }
   *out = r;
@@ -141,6 +144,8 @@ int lm_rollout_create(lm_rollout** out, lm_engine* env, int policy, const float*
 int lm_rollout_run(lm_rollout* r, int use_graph, void* stream) {
   if (!r) return -1;
   hipStream_t s = (hipStream_t)stream;
+  if (use_graph == LM_ROLLOUT_AUTO)      // a persistent block holds a whole CU (512 registers per lane): one resident generation of blocks, or the graph
+    use_graph = (r->persistent_ok && (r->N + 15) / 16 <= r->n_cu) ? LM_ROLLOUT_PERSISTENT : LM_ROLLOUT_GRAPH;
   if (!use_graph) return rollout_enqueue(r, s);
   if (use_graph == LM_ROLLOUT_PERSISTENT) {
     // the whole rollout in one kernel (un-randomised engines); same results as the other two modes

@@ -372,11 +372,12 @@ class Rollout:
         if rc != 0:
             raise EngineError(f"lm_rollout_create failed ({rc})")
 
-    MODES = {"enqueue": 0, "graph": 1, "persistent": 2}
+    MODES = {"enqueue": 0, "graph": 1, "persistent": 2, "auto": 3}
 
     def run(self, use_graph=True):
         """use_graph: False / "enqueue" (2T+1 launches), True / "graph" (one hipGraph replay) or "persistent" (the whole rollout in one kernel:
-        MLP policy on an un-randomised engine); identical buffers in all three modes."""
+        un-randomised engines; pays up to 16 envs x compute units = 4096 envs on MI355X) or "auto" (persistent where it pays, else the graph);
+        identical buffers in all modes."""
         mode = self.MODES[use_graph] if isinstance(use_graph, str) else (1 if use_graph else 0)
         rc = self.engine.lib.lm_rollout_run(self._h, mode, self.engine._stream())
         if rc != 0:

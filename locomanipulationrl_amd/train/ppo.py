@@ -77,8 +77,7 @@ class PPO:
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
             self.rollout = env._task.make_rollout(kind, self._packed, self._log_std, self.T, noise_seed=1000 + rank)
             ro = self.rollout
-            # one persistent kernel per rollout where the engine supports it (no domain randomisation), else the hipGraph replay
-            self._ro_mode = "graph" if env._task._dr_randomizer.randomize else "persistent"
+            self._ro_mode = "auto"      # one persistent kernel per rollout where the engine supports it and it pays, else the hipGraph replay
             self.b_obs, self.b_act, self.b_logp, self.b_rew = ro.obs[:self.T], ro.actions, ro.logp, ro.rewards
 
     # ------------------------------------------------------------------ policy evaluation

@@ -31,7 +31,7 @@ def main():
     o0 = torch.empty(N, 64, device="cuda"); eng.step(torch.zeros(N, 12, device="cuda"), None, o0)
     ro = Rollout(eng, kind, packed, log_std, T, noise_seed=3); ro.obs[0] = o0
     res = {"task": a.task, "num_envs": N, "T": T, "policy": a.policy}
-    modes = (("graph", True), ("enqueue", False), ("persistent", "persistent"))
+    modes = (("graph", True), ("enqueue", False), ("persistent", "persistent"), ("auto", "auto"))
     for name, graph in modes:
         for _ in range(3): ro.run(use_graph=graph); ro.obs[0].copy_(ro.obs[T])
         torch.cuda.synchronize(); t0 = time.perf_counter()
