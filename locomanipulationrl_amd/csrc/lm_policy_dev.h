@@ -249,6 +249,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
     for (int mb = 0; mb < 2; mb++)
 #pragma unroll
       for (int i = 0; i < 4; i++) bias1[mb][i] = b1[16 * mb + 4 * g + i];
+    __builtin_amdgcn_sched_barrier(0);      // issue the loads here, not at their first use
   };
   load_stage1(0);
   f32x4 h[NC][2];            // features of the owned nodes, C layout: h[j][mb][i] = feature 16 mb + 4 g + i of sample n
@@ -292,6 +293,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
 #pragma unroll
       for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
     }
+    __builtin_amdgcn_sched_barrier(0);
     // stage 1: P = W1[:, 0:32] h + b1, Q = W1[:, 32:64] h of the owned nodes -> LDS.
     // output feature block ob4 (0,1 = P rows 0..31; 2,3 = Q rows 0..31); k-step (mb', i) reads h[.][mb'][i] = feature 16 mb' + 4 g + i
     {
