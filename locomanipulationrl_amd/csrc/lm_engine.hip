@@ -1093,11 +1093,49 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
   }
 }
 
+// extras and success windows of the T steps of a persistent rollout, in step order: the accumulator rows are fetched (and cleared) 64 steps
+// at a time, the window counters live in registers across the steps; same arithmetic as finalize_extras
 __global__ void __launch_bounds__(64) k_rollout_finalize(const lm_params* params, OutPtrs W, int N, long long* acc_steps, float* extras, int T) {
-  for (int k = 0; k < T; k++) {
-    W.acc = acc_steps + 16 * k; W.out_extras = extras ? extras + (size_t)k * LM_NUM_EXTRAS : nullptr;
-    finalize_extras(params, W, N, threadIdx.x);
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // the window counters of step k are in memory before step k + 1 reads them
+  __shared__ long long sAcc[64 * 16];
+  const int lane = threadIdx.x;
+  int64_t* ns_g = reinterpret_cast<int64_t*>(W.stats); float* rate_g = reinterpret_cast<float*>(W.stats + 48);
+  int64_t ns[6]; float rate[3];
+#pragma unroll
+  for (int i = 0; i < 6; i++) ns[i] = ns_g[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) rate[i] = rate_g[i];
+  const int64_t max_cnt = (int64_t)params->max_reset_counts;
+  for (int k0 = 0; k0 < T; k0 += 64) {
+    const int nk = min(64, T - k0);
+    for (int i = lane; i < nk * 16; i += 64) {
+      sAcc[i] = __hip_atomic_load(acc_steps + 16 * (size_t)k0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(acc_steps + 16 * (size_t)k0 + i, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < nk; k++) {
+      const bool last = (k0 + k == T - 1);
+      float* ex = extras ? extras + (size_t)(k0 + k) * LM_NUM_EXTRAS : nullptr;
+      const long long tot = (lane < 14) ? sAcc[16 * k + lane] : 0;
+      const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
+      if (lane < 7) { float m = sum / (float)N; if (last) W.extras[lane] = m; if (ex) ex[lane] = m; }
+      if (lane >= 9 && lane < 12) { float m = sum / (float)N; if (last) W.extras[lane + 1] = m; if (ex) ex[lane + 1] = m; }
+      const float gsf = __shfl(sum, 7), rsf = __shfl(sum, 8), glf = __shfl(sum, 12), rlf = __shfl(sum, 13);
+      const int64_t gs = (int64_t)(gsf + 0.5f), rs = (int64_t)(rsf + 0.5f), gl = (int64_t)(glf + 0.5f), rl = (int64_t)(rlf + 0.5f);
+      success_window(ns + 0, rate + 0, gs, rs, max_cnt);
+      success_window(ns + 2, rate + 1, gl, rl, max_cnt);
+      success_window(ns + 4, rate + 2, gs - gl, rs - rl, max_cnt);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { if (last) W.extras[7 + c] = rate[c]; if (ex) ex[7 + c] = rate[c]; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) ns_g[i] = ns[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) rate_g[i] = rate[i];
   }
 }
 
