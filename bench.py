@@ -27,7 +27,7 @@ ROLLOUT = 48
 BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (460 read + 1028 written)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v5.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v6.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
 
 
 def cpu_baseline(steps: int = 150, envs: int = 4096):
