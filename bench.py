@@ -30,8 +30,9 @@ FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v6.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
 
 
-def cpu_baseline(steps: int = 150, envs: int = 4096):
-    """The CPU oracle (float32 build, OpenMP over envs) timed on this host on a bounded sample of the same workload."""
+def cpu_baseline(steps: int = 150, envs: int = 4096, params=None):
+    """The CPU oracle (float32 build, OpenMP over envs) timed on this host on a bounded sample of the same workload
+    (params: engine parameters of another task family, default = the headline locomotion task)."""
     import numpy as np
     from locomanipulationrl_amd.engine_config import loco_params
     from locomanipulationrl_amd.model.robot_model import load_model
@@ -39,7 +40,12 @@ def cpu_baseline(steps: int = 150, envs: int = 4096):
     cores = os.cpu_count() or 1
     cores = min(cores, 64)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    o = Oracle(load_model("quadruped_robot_v2"), loco_params(), "f32")
+    try:      # a second call in one process: the OpenMP runtime is already up and ignores the environment
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    o = Oracle(load_model("quadruped_robot_v2"), params or loco_params(), "f32")
     phys, task, cnt = o.new_state(envs)
     rng = np.random.default_rng(42)
     acts = rng.uniform(-1, 1, size=(steps + 2, envs, 12)).astype(np.float32)
