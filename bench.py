@@ -91,9 +91,13 @@ def main():
     from locomanipulationrl_amd.model.robot_model import load_model
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)                       # before the process group: RCCL binds to the current device
-    dev = torch.device("cuda", local_rank)
-    rank, local_rank, world = D.init_from_env()
+    # LM_BENCH_BACKEND=gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks (ranks then share devices); the
+    # measured configuration is always nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("LM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)                        # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", dev_index)
+    rank, local_rank, world = D.init_from_env(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     N = ENVS_PER_GPU
     eng = Engine(load_model("quadruped_robot_v2"), [loco_params()], N, seed=42 + rank, device=str(dev))
@@ -116,7 +120,8 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+            dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(dev)
 
     for t in range(args.warmup):
@@ -158,7 +163,7 @@ def main():
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if backend == "nccl" else "synthetic (REHEARSAL over gloo, ranks share GPUs: not a measurement)",
             "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
                                    "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
                        "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
@@ -172,7 +177,7 @@ def main():
         }
     eng.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
