@@ -21,8 +21,12 @@ def main():
     ap.add_argument("--no-hip", action="store_true", help="diagnostic: torch forward in the rollouts instead of the MFMA kernels")
     ap.add_argument("--no-fused", action="store_true", help="drive the rollout step by step from Python instead of the captured hipGraph")
     a = ap.parse_args()
-    local = int(os.environ.get("LOCAL_RANK", "0")); torch.cuda.set_device(local)
-    rank, local, world = D.init_from_env()
+    # LM_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("LM_DIST_BACKEND")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "gloo": local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    rank, _, world = D.init_from_env(backend)
     torch.manual_seed(a.seed + rank)
     env = lm.make_env(a.task, num_envs=a.num_envs, seed=a.seed, rank=rank, sim_device=f"cuda:{local}", rl_device=f"cuda:{local}")
     if a.policy == "gnn":
