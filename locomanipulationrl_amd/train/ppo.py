@@ -50,7 +50,7 @@ class RunningStandardScaler:
 class PPO:
     def __init__(self, env, model, rollouts=48, learning_epochs=5, mini_batches=1, gamma=0.99, lam=0.95, lr=3e-4, kl_threshold=0.012,
                  grad_norm_clip=1.0, ratio_clip=0.2, value_clip=0.2, value_loss_scale=1.0, entropy_loss_scale=0.0, hip_inference=True,
-                 fused_rollout=True, freeze_obs_scaler=False):
+                 fused_rollout=True, freeze_obs_scaler=False, max_lr=1e-2, min_log_std=None):
         self.env, self.model = env, model
         self.dev = next(model.parameters()).device
         self.N = env.num_envs
@@ -59,6 +59,7 @@ class PPO:
         self.gclip, self.rclip, self.vclip, self.vscale, self.escale = grad_norm_clip, ratio_clip, value_clip, value_loss_scale, entropy_loss_scale
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.freeze_obs_scaler = freeze_obs_scaler          # diagnostics: identity observation scaler (mean 0, var 1)
+        self.max_lr, self.min_log_std = max_lr, min_log_std  # diagnostics: cap of the KL-adaptive rate (skrl: 1e-2); floor of log_std (skrl: -20)
         self.n_obs = int(env.observation_space.shape[0])          # 88 for the custom-controller tasks
         self.obs_scaler = RunningStandardScaler(self.n_obs, self.dev); self.val_scaler = RunningStandardScaler(1, self.dev)
         # MFMA forward kernels: MLP on the 64- and 88-wide observations, GNN on the 64-wide one
@@ -152,13 +153,15 @@ class PPO:
                             p.grad.copy_(flat[o:o + p.numel()].view_as(p)); o += p.numel()
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gclip)
                 self.opt.step()
+                if self.min_log_std is not None:
+                    with torch.no_grad(): self.model.log_std_parameter.clamp_(min=self.min_log_std)
             kl = torch.stack(kls).mean()
             if self.world > 1:
                 dist.all_reduce(kl); kl /= self.world
             kl = float(kl)                                                        # KLAdaptiveRL (skrl): lr /= 1.5 above 2*thr, *= 1.5 below thr/2
             if self.kl_thr > 0:                                                   # kl_threshold 0 = fixed learning rate
                 if kl > self.kl_thr * 2: self.lr = max(self.lr / 1.5, 1e-6)
-                elif kl < self.kl_thr / 2: self.lr = min(self.lr * 1.5, 1e-2)
+                elif kl < self.kl_thr / 2: self.lr = min(self.lr * 1.5, self.max_lr)
             for gp in self.opt.param_groups: gp["lr"] = self.lr
             stats = {"kl": kl, "loss_pi": float(loss_pi), "loss_v": float(loss_v), "lr": self.lr}
         return stats

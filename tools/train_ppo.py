@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--no-obs-scaler", action="store_true", help="diagnostic: identity observation scaler")
     ap.add_argument("--no-hip", action="store_true", help="diagnostic: torch forward in the rollouts instead of the MFMA kernels")
     ap.add_argument("--no-fused", action="store_true", help="drive the rollout step by step from Python instead of the captured hipGraph")
+    ap.add_argument("--max-lr", type=float, default=1e-2, help="diagnostic: cap of the KL-adaptive learning rate (skrl default 1e-2)")
+    ap.add_argument("--min-log-std", type=float, default=None, help="diagnostic: floor of the log-std parameter (skrl clips at -20 only)")
     a = ap.parse_args()
     # LM_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("LM_DIST_BACKEND")
@@ -43,7 +45,7 @@ def main():
         inv = inv.to(f"cuda:{local}"); _step = env.step
         env.step = lambda act: _step(act[:, inv].contiguous())
         a.no_fused = True
-    ppo = PPO(env, model, hip_inference=hip and not a.no_hip, fused_rollout=not a.no_fused, **({"kl_threshold": 0.0} if a.fixed_lr else {}), freeze_obs_scaler=a.no_obs_scaler)
+    ppo = PPO(env, model, hip_inference=hip and not a.no_hip, fused_rollout=not a.no_fused, **({"kl_threshold": 0.0} if a.fixed_lr else {}), freeze_obs_scaler=a.no_obs_scaler, max_lr=a.max_lr, min_log_std=a.min_log_std)
     hist = ppo.train(a.timesteps, log_every=a.log_every, log=(lambda r: print(json.dumps(r), flush=True)) if rank == 0 else (lambda r: None))
     if rank == 0 and a.out:
         json.dump({"task": a.task, "num_envs": a.num_envs, "world": world, "policy": a.policy, "history": hist}, open(a.out, "w"), indent=1)
