@@ -122,7 +122,9 @@ typedef enum {
  *                use params[0] and [split_env, n_envs) use params[1] (co-train layout,
  *                joint_locomanipulation.py:25-34); split_env must be a multiple of 16.
  *   seed       : stream seed of the in-kernel goal sampler (replaces torch.rand in utils/math.py:184)
- * All envs start with reset_buf = 1 (rl_task.py:111). */
+ * All envs start with reset_buf = 1 (rl_task.py:111).
+ * The engine belongs to the device that is current in the calling thread here: every later call on the handle must be made with the
+ * same device current (one process per GPU) and returns LM_EINVAL otherwise instead of launching on another GPU. */
 int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks,
               int split_env, uint32_t seed);
 int lm_destroy(lm_engine* h);
