@@ -231,7 +231,8 @@ def test_fused_rollout_on_a_custom_controller_task():
 @pytest.mark.parametrize("task_name,N,policy", [("QuadrupedPoseControl", 512, "mlp"), ("QuadrupedPoseControl", 500, "mlp"), ("QuadrupedManipulatePlate", 256, "mlp"),
                                                 ("JointLocomanipulation", 512, "mlp"), ("QuadrupedPoseControlCustomController", 256, "mlp"),
                                                 ("JointLocomanipulationPositionControl", 256, "mlp"),
-                                                ("JointLocomanipulationVertical", 512, "gnn"), ("QuadrupedPoseControl", 500, "gnn")])
+                                                ("JointLocomanipulationVertical", 512, "gnn"), ("QuadrupedPoseControl", 500, "gnn"),
+                                                ("JointLocomanipulation", 8192, "mlp")])      # more blocks than compute units: two generations of blocks
 def test_persistent_rollout_kernel_equals_graph_replay(task_name, N, policy):
     """SURVEY 8 f-2, one-kernel form: every block keeps its 16 envs for the T steps (wavefront 0 steps them exactly like k_step, all four
     wavefronts run the policy tile -- MLP or GNN -- on the observations left in LDS) and the extras are published afterwards from per-step accumulators.  All
