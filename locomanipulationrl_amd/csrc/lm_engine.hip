@@ -1083,13 +1083,13 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
     }
     if (k == R.T) break;
     if (t < 64) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the sampled actions are in memory before the step reads them back
+      // (the sampled actions, the counters and the state are written and read back by this same wavefront: program order, no wait needed)
       B.actions = SA.actions; B.goal_rand = nullptr;
       B.W.out_obs = R.obs + (size_t)(k + 1) * Nk * NOBS; B.W.out_states = nullptr; B.W.out_rew = R.rewards + (size_t)k * Nk;
       B.W.out_resets = R.dones + (size_t)k * Nk; B.W.out_extras = nullptr; B.W.acc = R.acc_steps + 16 * k; B.W.defer_finalize = 1;
       step_dispatch(B, Pk, sTab, sObs, sSt, sStash);
     }
-    __syncthreads();        // the step's stores (state, counters, observations) are performed before anyone goes on
+    lds_barrier();          // the observations staged in LDS are visible to the other wavefronts; global data is private to wavefront 0
   }
 }
 

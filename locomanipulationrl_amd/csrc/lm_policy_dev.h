@@ -8,6 +8,15 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Block barrier for data exchanged through LDS only: waits for this wavefront's LDS operations, not for its global loads and stores
+// (__syncthreads() also drains vmcnt, which would stall every barrier on the weight prefetch that is deliberately kept in flight across it).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ELU with exp(x) - 1 on the hardware exponential (v_exp_f32): absolute error < 1e-7, against ~30 instructions for expm1f
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
@@ -142,26 +151,26 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
   float abuf[2][MLP_CH];
   int cur = 0;
   L1::issue(W1, wave, lane, 0, abuf[0]);
-  __syncthreads();
+  lds_barrier();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < L1::NCH; c++) {
     if (c + 1 < L1::NCH) L1::issue(W1, wave, lane, c + 1, abuf[cur ^ 1]); else L2::issue(W2, wave, lane, 0, abuf[cur ^ 1]);
     L1::compute(br1, sX, sH1, wave, n, g, true, c, abuf[cur], acc); cur ^= 1;
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int c = 0; c < L2::NCH; c++) {
     if (c + 1 < L2::NCH) L2::issue(W2, wave, lane, c + 1, abuf[cur ^ 1]); else L3::issue(W3, wave, lane, 0, abuf[cur ^ 1]);
     L2::compute(br2, sH1, sH2, wave, n, g, true, c, abuf[cur], acc); cur ^= 1;
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int c = 0; c < L3::NCH; c++) {
     if (c + 1 < L3::NCH) L3::issue(W3, wave, lane, c + 1, abuf[cur ^ 1]); else if (wave == 0) L4::issue(W4, 0, lane, 0, abuf[cur ^ 1]);
     L3::compute(br3, sH2, sH3, wave, n, g, true, c, abuf[cur], acc); cur ^= 1;
   }
-  __syncthreads();
+  lds_barrier();
   if (wave != 0) return;
   L4::compute(br4, sH3, sO, 0, n, g, false, 0, abuf[cur], acc);
   __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
@@ -316,7 +325,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
       }
     }
     if (layer < 2) load_stage1(layer + 1);
-    __syncthreads();
+    lds_barrier();
     // stage 2: messages along the edges that end in the owned nodes, max-aggregated
     {
 #pragma unroll
@@ -342,7 +351,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
         }
       }
     }
-    __syncthreads();       // every wavefront is done reading sPQ before the next layer overwrites it
+    lds_barrier();       // every wavefront is done reading sPQ before the next layer overwrites it
   }
   // ---- heads (:215-241): action mean of joint node j = Linear(32,1)(h[1+j]); value = Linear(32,1)(max over nodes)
   float wact[2][4];
@@ -376,7 +385,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
   // value head: max over all nodes = max over the four wavefronts' partial maxima
 #pragma unroll
   for (int i = 0; i < 4; i++) { sHm[((WAVE * 32) + 4 * g + i) * GNN_SAMPLES + n] = hm0[i]; sHm[((WAVE * 32) + 16 + 4 * g + i) * GNN_SAMPLES + n] = hm1[i]; }
-  __syncthreads();
+  lds_barrier();
   if (WAVE != 0) return;
   float v = 0.f;
 #pragma unroll
