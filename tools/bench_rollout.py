@@ -17,18 +17,18 @@ def main():
                                                                    "--task JointLocomanipulationVertical --num-envs 8192 --policy gnn)")
     a = ap.parse_args()
     N, T = a.num_envs, a.T
-    if a.policy == "mlp":
-        from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params, mlp_forward_hip as fwd
-        model = SharedMLP().cuda(); packed = pack_mlp_params(model, None, None).cuda(); kind = POLICY_MLP
-    else:
-        from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params, gnn_forward_hip as fwd
-        model = GraphPolicy().cuda(); packed = pack_gnn_params(model.net, model.mean_layer, model.value_layer).cuda(); kind = POLICY_GNN
-    log_std = torch.full((12,), -0.5, device="cuda")
     from locomanipulationrl_amd.utils.config import SimConfig, load_config
     from locomanipulationrl_amd.utils.task_util import task_map
     task = task_map()[a.task](name=a.task, sim_config=SimConfig(load_config(a.task, num_envs=N)), env=None)
     eng = Engine(load_model(task.model_asset), task.engine_params(), N, split_env=task.split_env(), seed=1)
-    o0 = torch.empty(N, 64, device="cuda"); eng.step(torch.zeros(N, 12, device="cuda"), None, o0)
+    if a.policy == "mlp":
+        from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params, mlp_forward_hip as fwd
+        model = SharedMLP(num_observations=eng.num_obs).cuda(); packed = pack_mlp_params(model, None, None).cuda(); kind = POLICY_MLP
+    else:
+        from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params, gnn_forward_hip as fwd
+        model = GraphPolicy().cuda(); packed = pack_gnn_params(model.net, model.mean_layer, model.value_layer).cuda(); kind = POLICY_GNN
+    log_std = torch.full((12,), -0.5, device="cuda")
+    o0 = torch.empty(N, eng.num_obs, device="cuda"); eng.step(torch.zeros(N, 12, device="cuda"), None, o0)
     ro = Rollout(eng, kind, packed, log_std, T, noise_seed=3); ro.obs[0] = o0
     res = {"task": a.task, "num_envs": N, "T": T, "policy": a.policy}
     modes = (("graph", True), ("enqueue", False), ("persistent", "persistent"), ("auto", "auto"))
@@ -38,7 +38,7 @@ def main():
         for _ in range(a.reps): ro.run(use_graph=graph); ro.obs[0].copy_(ro.obs[T])
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.reps
         res[name] = {"ms_per_rollout": dt * 1e3, "us_per_step": dt / T * 1e6, "env_steps_per_s": N * T / dt}
-    obs = ro.obs[T].clone(); o = torch.empty(N, 64, device="cuda"); r = torch.empty(N, device="cuda"); d = torch.empty(N, dtype=torch.int64, device="cuda")
+    obs = ro.obs[T].clone(); o = torch.empty(N, eng.num_obs, device="cuda"); r = torch.empty(N, device="cuda"); d = torch.empty(N, dtype=torch.int64, device="cuda")
     def py_rollout(obs):
         for t in range(T):
             mean, value = fwd(obs, packed); act, logp = sample_actions(eng, mean, log_std, 3); eng.step(act, None, o, None, r, d); obs = o
