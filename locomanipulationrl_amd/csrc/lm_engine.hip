@@ -647,8 +647,7 @@ LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
 
 struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms; float *out_obs, *out_states, *out_rew; int64_t* out_resets;
                  long long* acc;          // int64 [16]: fixed-point sums of the 12 per-env terms, first-task shares of goal_reset / reset, -, arrival ticket
-                 char* stats; float* extras; float* out_extras; int split_block;
-                 int defer_finalize; };   // 1: only accumulate; the extras of this step are published later (persistent rollout kernel)
+                 char* stats; float* extras; float* out_extras; int split_block; };
 #define ACC_SCALE 1048576.0f      // 2^20: integer accumulation makes the means independent of the arrival order (bitwise reproducible)
 
 LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
@@ -679,7 +678,7 @@ LM_DEV void finalize_extras(const lm_params* __restrict__ P, const OutPtrs& W, i
 
 struct DrOut { int64_t* drc; uint32_t seed, dr_step; int64_t rand_buf, reset_key; uint32_t* sKey; };      // sKey: LDS [16][2] {corr key, fire}
 
-template <int DR>
+template <int DR, int DEFER = 0>      // DEFER 1: only accumulate; the extras of this step are published later (persistent rollout kernel)
 LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int N, int env0, int lane, int limb, int env, bool active,
                           const TaskState& S, const TaskOut& O, int64_t* cnt, int episode, float* sObs, float* sSt, const DrOut& DO) {
   if (DR) {
@@ -762,7 +761,7 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
 #pragma unroll
     for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
   }
-  if (!W.defer_finalize) {
+  if (!DEFER) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's atomics (and its stores) have been performed
     asm volatile("" :: "v"(dummy));
     int ticket = 0;
@@ -805,7 +804,7 @@ struct StepArgs {
   float* dr_phys;   // [LM_DR_PHYS_ROWS][N] attributes sampled for this step (k_step_dr only)
 };
 
-template <int MODE, int VAR, int DR>
+template <int MODE, int VAR, int DR, int DEFER = 0>
 LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float* sTab, float* sObs, float* sSt, float4* sStash) {
   TableRegs TR; table_fetch(A.table, threadIdx.x, TR);
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
@@ -1005,7 +1004,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   }
   DrOut DO; DO.drc = A.drc; DO.seed = A.seed; DO.dr_step = dr_step; DO.rand_buf = dr_rand_buf; DO.reset_key = dr_reset_key;
   DO.sKey = reinterpret_cast<uint32_t*>(sStash);      // the stash is dead after the last sub-step
-  write_outputs<DR>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
+  write_outputs<DR, DEFER>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
 }
 
 __global__ void __launch_bounds__(64) k_step(StepArgs A) {
@@ -1048,9 +1047,9 @@ struct RolloutDev {
 
 // the step of the persistent kernel as a real call: its ~350 registers are then allocated separately from the policy tile's
 LM_DEV void step_dispatch(const StepArgs& B, const lm_params* P, float* sTab, float* sObs, float* sSt, float4* sStash) {
-  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(B, P, sTab, sObs, sSt, sStash); }
-  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0>(B, P, sTab, sObs, sSt, sStash); }
-  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 0>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(B, P, sTab, sObs, sSt, sStash); }
+  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0, 1>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0, 1>(B, P, sTab, sObs, sSt, sStash); }
+  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0, 1>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0, 1>(B, P, sTab, sObs, sSt, sStash); }
+  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 0, 1>(B, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0, 1>(B, P, sTab, sObs, sSt, sStash); }
 }
 
 template <int NOBS, int POLICY> struct PolicySmem { MlpSmem<NOBS> M; };
@@ -1086,7 +1085,7 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
       // (the sampled actions, the counters and the state are written and read back by this same wavefront: program order, no wait needed)
       B.actions = SA.actions; B.goal_rand = nullptr;
       B.W.out_obs = R.obs + (size_t)(k + 1) * Nk * NOBS; B.W.out_states = nullptr; B.W.out_rew = R.rewards + (size_t)k * Nk;
-      B.W.out_resets = R.dones + (size_t)k * Nk; B.W.out_extras = nullptr; B.W.acc = R.acc_steps + 16 * k; B.W.defer_finalize = 1;
+      B.W.out_resets = R.dones + (size_t)k * Nk; B.W.out_extras = nullptr; B.W.acc = R.acc_steps + 16 * k;
       step_dispatch(B, Pk, sTab, sObs, sSt, sStash);
     }
     lds_barrier();          // the observations staged in LDS are visible to the other wavefronts; global data is private to wavefront 0
@@ -1450,7 +1449,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   StepArgs A;
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
   A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.acc = h->d_acc;
-  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE; A.W.defer_finalize = 0;
+  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
   A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
   return A;
