@@ -119,7 +119,7 @@ def _cotrain_params(kind, N):
     return cls(name=name, sim_config=SimConfig(load_config(name, num_envs=N)), env=None).engine_params()
 
 
-@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "cotrain", "cotrain_pc"])
+@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "cotrain", "cotrain_pc", "loco_v", "mani_v"])
 def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
     """lm_task_eval (the kernel's task layer on supplied read-back states) against the reference's own Python for every task
     family: velocity drive, custom controller, position control (single tasks: their `actions[:] = 0` line == action scale 0),
@@ -128,6 +128,11 @@ def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
     T, N = g["rew"].shape
     if kind.startswith("cotrain"):
         params = _cotrain_params(kind, N); split = N // 2
+    elif kind.endswith("_v"):      # vertical configuration: parameters as the host task classes build them
+        from locomanipulationrl_amd.utils.config import SimConfig, load_config
+        from locomanipulationrl_amd.utils.task_util import task_map
+        name = {"loco_v": "QuadrupedPoseControlVertical", "mani_v": "QuadrupedManipulatePlateVertical"}[kind]
+        params = task_map()[name](name=name, sim_config=SimConfig(load_config(name, num_envs=N)), env=None).engine_params(); split = None
     else:
         params = [{"loco": loco_params, "mani": mani_params, "loco_cc": loco_cc_params, "mani_cc": mani_cc_params,
                    "loco_pc": lambda: loco_pc_params(act_scale_se=0.0), "mani_pc": lambda: mani_pc_params(act_scale_se=0.0)}[kind]()]; split = None

@@ -18,15 +18,26 @@ EXTRAS_TO_TERM = {"env/rewards/action_rate_penalty": 3, "env/rewards/consecutive
                   "env/rewards/translation_penalty": 1, "env/rewards/mechanical_power_penalty": 8,
                   "env/rewards/position_target_error_penalty": 9, "env/rewards/rot_dist_decreasing_reward": 10}
 # the two single-task position-control files zero the actions before integrating them (…position_control.py:261): action scale 0
+def _host_task_params(name):
+    """Engine parameters exactly as the host task class builds them (the vertical configuration lives in the task classes)."""
+    from locomanipulationrl_amd.utils.config import SimConfig, load_config
+    from locomanipulationrl_amd.utils.task_util import task_map
+    return task_map()[name](name=name, sim_config=SimConfig(load_config(name, num_envs=32)), env=None).engine_params()[0]
+
+
 PARAMS = {"loco": loco_params, "mani": mani_params, "loco_cc": loco_cc_params, "mani_cc": mani_cc_params,
-          "loco_pc": lambda: loco_pc_params(act_scale_se=0.0), "mani_pc": lambda: mani_pc_params(act_scale_se=0.0)}
+          "loco_pc": lambda: loco_pc_params(act_scale_se=0.0), "mani_pc": lambda: mani_pc_params(act_scale_se=0.0),
+          # vertical configuration: goldens from quadruped_pose_control_vertical.py / quadruped_manipulate_plate_vertical.py (fed zero actions:
+          # those files zero their argument in place, :204 / :214)
+          "loco_v": lambda: _host_task_params("QuadrupedPoseControlVertical"), "mani_v": lambda: _host_task_params("QuadrupedManipulatePlateVertical")}
 
 
-@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc"])
+@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "loco_v", "mani_v"])
 def test_task_layer_sequence(robot_model, kind):
     """loco / mani: the velocity-drive tasks; *_cc: the custom-controller family, whose reference code is
     quadruped_pose_control_custom_controller.py / quadruped_manipulate_plate_custom_controller.py; *_pc: the position-control
-    family (quadruped_pose_control_position_control.py / quadruped_manipulate_plate_position_control.py)."""
+    family (quadruped_pose_control_position_control.py / quadruped_manipulate_plate_position_control.py); *_v: the vertical configuration
+    (symmetric dof1 windows, its own corner points and rest heights)."""
     g = np.load(os.path.join(GOLDEN, f"task_{kind}.npz"))
     ep = PARAMS[kind](); pc = kind.endswith("_pc"); cc = kind.endswith("_cc") or pc
     o = Oracle(robot_model, ep)

@@ -189,6 +189,12 @@ def make_task(kind, N):
     elif kind == "loco":
         from tasks.quadruped_pose_control_tasks.quadruped_pose_control import QuadrupedPoseControl as T
         mangle = "_QuadrupedPoseControl"
+    elif kind == "loco_v":
+        from tasks.quadruped_pose_control_tasks.quadruped_pose_control_vertical import QuadrupedPoseControlVertical as T
+        mangle = "_QuadrupedPoseControlVertical"
+    elif kind == "mani_v":
+        from tasks.quadruped_manipulate_plate.quadruped_manipulate_plate_vertical import QuadrupedManipulatePlateVertical as T
+        mangle = "_QuadrupedManipulatePlateVertical"
     else:
         from tasks.quadruped_manipulate_plate.quadruped_manipulate_plate import QuadrupedManipulatePlate as T
         mangle = "_QuadrupedManipulatePlate"
@@ -206,9 +212,10 @@ def make_task(kind, N):
     t.last_base_tip_positions = z(N, 4, 3)
     t.default_base_tip_positions = torch.tensor([[-0.0937, 0.1223, -0.1774], [0.0937, 0.1408, -0.1773],
                                                  [-0.0937, -0.1408, -0.1773], [0.0937, -0.1223, -0.1774]]).repeat((N, 1, 1))
-    corner = torch.cat((torch.tensor([0.075, 0.1835, -0.04]).repeat(N, 1), torch.tensor([-0.075, 0.1835, -0.04]).repeat(N, 1),
-                        torch.tensor([0.075, -0.1835, -0.04]).repeat(N, 1), torch.tensor([-0.075, -0.1835, -0.04]).repeat(N, 1)),
-                       dim=-1).view(N, 4, 3).to(torch.float32)
+    vert = kind.endswith("_v")
+    cpts = [[0.0, -0.115, -0.1853], [0.0, 0.115, -0.1853], [-0.115, 0.0, -0.1853], [0.115, 0.0, -0.1853]] if vert else \
+        [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04], [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]]      # (…_vertical.py:122-127 / :132-137)
+    corner = torch.cat([torch.tensor(c).repeat(N, 1) for c in cpts], dim=-1).view(N, 4, 3).to(torch.float32)
     setattr(t, mangle + "__corner_pos_robot", corner)
     t.goal_quaternions = z(N, 4)
     t.successes, t.consecutive_successes, t.goal_reset_buf = z(N, dt=torch.long), z(N, dt=torch.long), z(N, dt=torch.long)
@@ -217,6 +224,8 @@ def make_task(kind, N):
     t.success_rate = torch.tensor(0.0)
     t.randomization_buf = z(N, dt=torch.long)
     init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4)
+    if vert:   # class-default pose of the vertical robot (robot/quadruped_robot.py:81-87); the vertical task files do not override it
+        init_q = torch.tensor([0.0] * 4 + [0.35, -0.35] * 4 + [0.95, -0.95] * 4)
     if cc:   # class-default pose (robot/quadruped_robot.py:45-52); custom-controller state (…_custom_controller.py:175-195)
         init_q = torch.tensor([-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92] + [0.953, -0.953] * 4)
         t.current_joint_position_targets = init_q[:12].repeat(N, 1).clone()
@@ -240,22 +249,22 @@ def make_task(kind, N):
         else:
             t.joint_positions_mani = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_mani = torch.zeros(N, 12)
     zfix = 0.3 if kind == "mani_pc" else 0.0
-    if kind in ("loco", "loco_cc", "loco_pc"):
+    if kind in ("loco", "loco_cc", "loco_pc", "loco_v"):
         t.robot_locomotion = FakeRobot(N)
         t.pose_indicator_loco = FakeObj(N)
         t.default_joint_positions_loco = init_q.repeat((N, 1))
-        t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.18 if cc else 0.14]).repeat((N, 1))
+        t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.35 if vert else (0.18 if cc else 0.14)]).repeat((N, 1))
         t.default_robot_quaternions_loco = torch.tensor([1.0, 0, 0, 0]).repeat((N, 1))
-        t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
+        t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.4 if vert else 0.3]]).repeat((N, 1))
     else:
         t.robot_manipulation = FakeRobot(N)
         t.pose_indicator_mani = FakeObj(N); t.obj = FakeObj(N)
         t.default_joint_positions_mani = init_q.repeat((N, 1))
         t.default_robot_positions_mani = torch.tensor([0.0, 0.0, zfix]).repeat((N, 1))
         t.default_robot_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
-        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.44 if pc else (0.18 if cc else 0.14)]).repeat((N, 1))
+        t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.35 if vert else (0.44 if pc else (0.18 if cc else 0.14))]).repeat((N, 1))
         t.default_obj_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((N, 1))
-        t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((N, 1))
+        t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.4 if vert else 0.3]]).repeat((N, 1))
         setattr(t, mangle + "__corner_pos_world",
                 transform_vectors(t.default_robot_quaternions_mani, t.default_robot_positions_mani, corner, dev))
     return t
@@ -270,14 +279,18 @@ def gen_task(kind, N=32, T=26, seed=7):
     cc = kind.endswith("_cc"); pc = kind.endswith("_pc"); base_kind = kind[:4]
     zfix = 0.3 if kind == "mani_pc" else 0.0
     robot = t.robot_locomotion if base_kind == "loco" else t.robot_manipulation
+    vert = kind.endswith("_v")
     init_q = torch.tensor([-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]) if cc else \
         torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
+    if vert: init_q = torch.tensor([0.0] * 4 + [0.35, -0.35] * 4)
+    zb = 0.30 if vert else 0.13            # nominal height of the free body in the synthetic read-back (vertical: corners hang 0.185 below the base)
     rec = {k: [] for k in ("readback", "actions", "goal_rand", "obs", "states", "rew", "reset_buf", "goal_reset_buf",
                            "successes", "consecutive_successes", "progress_buf", "last_actions", "last_base_tip",
                            "goal_quaternions", "extras", "success_rate", "num_successes", "num_resets", "joint_reset", "torque", "se", "last_targets", "last_rot_dist")}
     extras_keys = None
     for step in range(T):
         actions = (torch.rand(N, 12, generator=g) * 2 - 1).clamp(-1, 1)
+        if vert: actions = torch.zeros(N, 12)      # the vertical files zero their argument in place (…_vertical.py:204): feed zeros
         # ---- pre_physics_step (resets flagged envs; consumes the global RNG exactly like the reference)
         ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
         goal_rand = torch.zeros(N, 3)
@@ -291,9 +304,11 @@ def gen_task(kind, N=32, T=26, seed=7):
         q[0:4, 5] = q[0:4, 4] - torch.tensor([0.40, 0.39, 2.55, 2.62])        # |dof3-dof2| around penalty/reset windows
         q[4:8, 0] = torch.tensor([-2.40, -2.45, 0.80, 0.90])                  # a1 dof1 windows
         q[8:12, 1] = torch.tensor([2.40, 2.45, -0.80, -0.90])                 # a2 dof1 mirrored windows
+        if vert:                                                              # symmetric windows +-2.09 / +-2.26 on all four dof1 (…_vertical.py:84-87,452-459)
+            q[4:8, 0] = torch.tensor([-2.10, -2.27, 2.08, 2.25]); q[8:12, 1] = torch.tensor([2.10, 2.27, -2.08, -2.25])
         qd = 2.0 * torch.randn(N, 12, generator=g)
         acc = 20.0 * torch.randn(N, 12, generator=g)
-        pos = torch.cat((0.05 * torch.randn(N, 2, generator=g), 0.13 + 0.02 * torch.randn(N, 1, generator=g)), dim=-1)
+        pos = torch.cat((0.05 * torch.randn(N, 2, generator=g), zb + 0.02 * torch.randn(N, 1, generator=g)), dim=-1)
         quat = _rand_unit_quat(g, N, small=0.25)
         pos[12, 2] = 0.049; pos[13, 2] = 0.051                                  # base height threshold
         quat[14] = torch.tensor([0.0, 1.0, 0.0, 0.0])                           # upside down -> ground above robot
@@ -319,7 +334,7 @@ def gen_task(kind, N=32, T=26, seed=7):
             flip = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(len(track), 1)
             quat[track] = quat_mul(flip, quat_mul(small, goal))         # conj(q_r) (x) pq = small (x) goal
         quat = quat / quat.norm(dim=-1, keepdim=True)
-        pos[track] = torch.tensor([0.0, 0.0, 0.13]); q[track] = init_q
+        pos[track] = torch.tensor([0.0, 0.0, zb]); q[track] = init_q
         knees[track, :, 2] = 0.1 if base_kind == "loco" else 0.02
         robot.joint_positions, robot.joint_velocities, robot.joint_accelerations = q, qd, acc
         robot.tip_positions, robot.knee_positions = tips, knees
@@ -639,8 +654,8 @@ def main():
     _install_placeholders()
     sys.path[:0] = [REF_RL, os.path.dirname(REF_RL)]
     os.makedirs(OUT, exist_ok=True)
-    for kind in ("loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc"):
-        d = gen_task(kind, T=26 if kind in ("loco", "mani") else 32)
+    for kind in ("loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "loco_v", "mani_v"):
+        d = gen_task(kind, T=26 if kind in ("loco", "mani", "loco_v", "mani_v") else 32)
         np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
         print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "states", "rew", "extras")},
               "resets/step", d["reset_buf"].sum(1)[:8], "max consec", d["consecutive_successes"].max(),
