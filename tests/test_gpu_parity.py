@@ -112,14 +112,14 @@ def test_contact_free_dynamics_tight(robot_model, engine_cls, oracle_cls, mode):
 def _cotrain_params(kind, N):
     from locomanipulationrl_amd.utils.config import SimConfig, load_config
     from locomanipulationrl_amd.utils.task_util import task_map
-    name = {"cotrain": "JointLocomanipulation", "cotrain_pc": "JointLocomanipulationPositionControl"}[kind]
+    name = {"cotrain": "JointLocomanipulation", "cotrain_pc": "JointLocomanipulationPositionControl", "cotrain_v": "JointLocomanipulationVertical"}[kind]
     cls = task_map()[name]
     if kind == "cotrain":      # the committed file pins the goal to one orientation (joint_locomanipulation.py:61-66)
         cls = type("PinnedGoal", (cls,), dict(min_roll=0.2, max_roll=0.2, min_pitch=0.2, max_pitch=0.2, min_yaw=0.785, max_yaw=0.785))
     return cls(name=name, sim_config=SimConfig(load_config(name, num_envs=N)), env=None).engine_params()
 
 
-@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "cotrain", "cotrain_pc", "loco_v", "mani_v"])
+@pytest.mark.parametrize("kind", ["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc", "cotrain", "cotrain_pc", "loco_v", "mani_v", "cotrain_v"])
 def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
     """lm_task_eval (the kernel's task layer on supplied read-back states) against the reference's own Python for every task
     family: velocity drive, custom controller, position control (single tasks: their `actions[:] = 0` line == action scale 0),

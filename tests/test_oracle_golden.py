@@ -72,16 +72,17 @@ def test_task_layer_sequence(robot_model, kind):
     assert g["consecutive_successes"].max() > ep.max_consec and (g["rew"] > 300).any(), "bonus path must be exercised"
 
 
-@pytest.mark.parametrize("kind", ["cotrain", "cotrain_pc"])
+@pytest.mark.parametrize("kind", ["cotrain", "cotrain_pc", "cotrain_v"])
 def test_cotrain_task_layer_sequence(kind):
     """The co-training tasks (a14; f-1 for the position-control variant): goldens from joint_locomanipulation.py /
-    joint_locomanipulation_position_control.py; parameters exactly as the host task classes build them; envs [0, N/2) are
+    joint_locomanipulation_position_control.py / joint_locomanipulation_vertical.py (fed zero actions: it zeroes its argument in place);
+    parameters exactly as the host task classes build them; envs [0, N/2) are
     evaluated with the locomotion block, [N/2, N) with the manipulation block."""
     from locomanipulationrl_amd.model.robot_model import load_model
     from locomanipulationrl_amd.utils.config import SimConfig, load_config
     from locomanipulationrl_amd.utils.task_util import task_map
     g = np.load(os.path.join(GOLDEN, f"task_{kind}.npz"))
-    name = {"cotrain": "JointLocomanipulation", "cotrain_pc": "JointLocomanipulationPositionControl"}[kind]
+    name = {"cotrain": "JointLocomanipulation", "cotrain_pc": "JointLocomanipulationPositionControl", "cotrain_v": "JointLocomanipulationVertical"}[kind]
     T, N = g["rew"].shape; h = N // 2; pc = kind == "cotrain_pc"
     cls = task_map()[name]
     if kind == "cotrain":      # the committed file pins the goal to one orientation (joint_locomanipulation.py:61-66); the host class keeps the

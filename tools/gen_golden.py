@@ -376,10 +376,13 @@ def gen_task(kind, N=32, T=26, seed=7):
 # ----------------------------------------------------------------------------- co-training tasks (a14, f-1)
 def make_cotrain_task(kind, N):
     """JointLocomanipulation / JointLocomanipulationPositionControl on fakes: envs [0, N/2) locomotion, [N/2, N) manipulation."""
-    pc = kind == "cotrain_pc"
+    pc = kind == "cotrain_pc"; vert = kind == "cotrain_v"
     if pc:
         from tasks.joint_train_locomanipulation.joint_locomanipulation_position_control import JointLocomanipulationPositionControl as T
         mangle = "_JointLocomanipulationPositionControl"
+    elif vert:
+        from tasks.joint_train_locomanipulation.joint_locomanipulation_vertical import JointLocomanipulationVertical as T
+        mangle = "_JointLocomanipulationVertical"
     else:
         from tasks.joint_train_locomanipulation.joint_locomanipulation import JointLocomanipulation as T
         mangle = "_JointLocomanipulation"
@@ -399,9 +402,9 @@ def make_cotrain_task(kind, N):
     t.last_base_tip_positions = z(N, 4, 3)
     t.default_base_tip_positions = torch.tensor([[-0.0937, 0.1223, -0.1774], [0.0937, 0.1408, -0.1773],
                                                  [-0.0937, -0.1408, -0.1773], [0.0937, -0.1223, -0.1774]]).repeat((N, 1, 1))
-    corner = torch.cat((torch.tensor([0.075, 0.1835, -0.04]).repeat(h, 1), torch.tensor([-0.075, 0.1835, -0.04]).repeat(h, 1),
-                        torch.tensor([0.075, -0.1835, -0.04]).repeat(h, 1), torch.tensor([-0.075, -0.1835, -0.04]).repeat(h, 1)),
-                       dim=-1).view(h, 4, 3).to(torch.float32)
+    cpts = [[0.0, -0.115, -0.1853], [0.0, 0.115, -0.1853], [-0.115, 0.0, -0.1853], [0.115, 0.0, -0.1853]] if vert else \
+        [[0.075, 0.1835, -0.04], [-0.075, 0.1835, -0.04], [0.075, -0.1835, -0.04], [-0.075, -0.1835, -0.04]]      # (joint_locomanipulation_vertical.py:147-152 / :178-183)
+    corner = torch.cat([torch.tensor(c).repeat(h, 1) for c in cpts], dim=-1).view(h, 4, 3).to(torch.float32)
     setattr(t, mangle + "__corner_pos_robot", corner)
     t.goal_quaternions = z(N, 4)
     t.successes, t.consecutive_successes, t.goal_reset_buf = z(N, dt=torch.long), z(N, dt=torch.long), z(N, dt=torch.long)
@@ -411,17 +414,18 @@ def make_cotrain_task(kind, N):
         setattr(t, "success_rate" + sfx, torch.tensor(0.0))
     t.randomization_buf = z(N, dt=torch.long)
     init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09] + [1.37, -1.37] * 4)
+    if vert: init_q = torch.tensor([0.0] * 4 + [0.35, -0.35] * 4 + [0.95, -0.95] * 4)          # robot/quadruped_robot.py:81-87
     t.robot_locomotion, t.robot_manipulation = FakeRobot(h), FakeRobot(h)
     t.pose_indicator_loco, t.pose_indicator_mani, t.obj = FakeObj(h), FakeObj(h), FakeObj(h)
     t.default_joint_positions_loco = init_q.repeat((h, 1)); t.default_joint_positions_mani = init_q.repeat((h, 1))
-    t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.14]).repeat((h, 1))
+    t.default_robot_positions_loco = torch.tensor([0.0, 0.0, 0.35 if vert else 0.14]).repeat((h, 1))
     t.default_robot_quaternions_loco = torch.tensor([1.0, 0, 0, 0]).repeat((h, 1))
-    t.default_robot_positions_mani = torch.tensor([0.0, 0.0, 0.5]).repeat((h, 1))           # joint_locomanipulation.py:139
+    t.default_robot_positions_mani = torch.tensor([0.0, 0.0, 0.6 if vert else 0.5]).repeat((h, 1))           # joint_locomanipulation.py:139, …_vertical.py:108
     t.default_robot_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((h, 1))
-    t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.64 if pc else 0.68]).repeat((h, 1))
+    t.default_obj_positions_mani = torch.tensor([0.0, 0.0, 0.95 if vert else (0.64 if pc else 0.68)]).repeat((h, 1))
     t.default_obj_quaternions_mani = torch.tensor([0.0, 1.0, 0, 0]).repeat((h, 1))
-    t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.3]]).repeat((h, 1))
-    t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 0.8]]).repeat((h, 1))
+    t.default_pose_indicator_loco_positions = torch.tensor([[0.0, 0.0, 0.5 if vert else 0.3]]).repeat((h, 1))
+    t.default_pose_indicator_mani_positions = torch.tensor([[0.0, 0.0, 1.1 if vert else 0.8]]).repeat((h, 1))
     setattr(t, mangle + "__corner_pos_world", transform_vectors(t.default_robot_quaternions_mani, t.default_robot_positions_mani, corner, "cpu"))
     if pc:   # joint_locomanipulation_position_control.py:218-243
         t.joint_positions_combined = init_q[:12].repeat(N, 1).clone(); t.joint_velocities_combined = z(N, 12)
@@ -434,13 +438,15 @@ def make_cotrain_task(kind, N):
     return t
 
 
-def _synth_half(g, mani, n, init_q, goal, zfix):
+def _synth_half(g, mani, n, init_q, goal, zfix, vert=False):
     """Synthetic read-back state of one half (n envs), straddling the thresholds of Appendix D; envs n-6.. track their goal."""
     from omni.isaac.core.utils.torch.rotations import quat_conjugate, quat_mul
     q = init_q.repeat(n, 1) + 0.25 * torch.randn(n, 12, generator=g)
     q[0:2, 5] = q[0:2, 4] - torch.tensor([0.40, 2.62]); q[2:4, 0] = torch.tensor([-2.40, 0.90]); q[4:6, 1] = torch.tensor([2.40, -0.90])
+    if vert: q[2:4, 0] = torch.tensor([-2.27, 2.10]); q[4:6, 1] = torch.tensor([2.27, -2.10])      # symmetric dof1 windows of the vertical files
+    zb = 0.30 if vert else 0.13
     qd = 2.0 * torch.randn(n, 12, generator=g); acc = 20.0 * torch.randn(n, 12, generator=g)
-    pos = torch.cat((0.05 * torch.randn(n, 2, generator=g), 0.13 + 0.02 * torch.randn(n, 1, generator=g)), dim=-1)
+    pos = torch.cat((0.05 * torch.randn(n, 2, generator=g), zb + 0.02 * torch.randn(n, 1, generator=g)), dim=-1)
     quat = _rand_unit_quat(g, n, small=0.25)
     lin = 0.3 * torch.randn(n, 3, generator=g); ang = 1.0 * torch.randn(n, 3, generator=g)
     tips = 0.15 * torch.randn(n, 4, 3, generator=g)
@@ -461,7 +467,7 @@ def _synth_half(g, mani, n, init_q, goal, zfix):
     else:
         quat[track] = quat_conjugate(quat_mul(small, goal[track]))
     quat = quat / quat.norm(dim=-1, keepdim=True)
-    pos[track] = torch.tensor([0.0, 0.0, 0.13]); q[track] = init_q
+    pos[track] = torch.tensor([0.0, 0.0, zb]); q[track] = init_q
     knees[track, :, 2] = 0.02 if mani else 0.1
     knees[track, :, :2] *= 0.2          # keep the tracking envs' knees clear of the tilted plate so they reach the bonus
     pos[:, 2] += zfix; tips[:, :, 2] += zfix; knees[:, :, 2] += zfix
@@ -472,13 +478,15 @@ def gen_cotrain(kind, N=32, T=30, seed=13):
     """The co-training tasks through T post-physics evaluations (same protocol as gen_task; both halves in one call)."""
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
-    t = make_cotrain_task(kind, N); h = N // 2; pc = kind == "cotrain_pc"
+    t = make_cotrain_task(kind, N); h = N // 2; pc = kind == "cotrain_pc"; vert = kind == "cotrain_v"
     init_q = torch.tensor([-1.57, 1.57, 1.57, -1.57, -1.04, -2.09, 2.09, 1.04, 2.09, 1.04, -1.04, -2.09])
+    if vert: init_q = torch.tensor([0.0] * 4 + [0.35, -0.35] * 4)
     rec = {k: [] for k in ("readback", "actions", "goal_rand", "obs", "rew", "reset_buf", "goal_reset_buf", "successes", "consecutive_successes",
                            "progress_buf", "last_actions", "last_base_tip", "goal_quaternions", "extras", "joint_reset", "se", "last_targets", "torque")}
     extras_keys = None
     for step in range(T):
         actions = (torch.rand(N, 12, generator=g) * 2 - 1).clamp(-1, 1)
+        if vert: actions = torch.zeros(N, 12)      # the vertical file zeroes both halves of its argument in place (:258-259)
         # reset_idx draws the locomotion goals first, then the manipulation goals (joint_locomanipulation.py:319-334)
         ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
         goal_rand = torch.zeros(N, 3)
@@ -488,8 +496,8 @@ def gen_cotrain(kind, N=32, T=30, seed=13):
             goal_rand[il] = torch.rand((len(il), 3)); goal_rand[im] = torch.rand((len(im), 3))
             torch.set_rng_state(st)
         t.pre_physics_step(actions.clone())
-        ql, qdl, accl, posl, quatl, linl, angl, tipsl, kneesl = _synth_half(g, False, h, init_q, t.goal_quaternions[:h], 0.0)
-        qm, qdm, accm, posm, quatm, linm, angm, tipsm, kneesm = _synth_half(g, True, h, init_q, t.goal_quaternions[h:], 0.5)
+        ql, qdl, accl, posl, quatl, linl, angl, tipsl, kneesl = _synth_half(g, False, h, init_q, t.goal_quaternions[:h], 0.0, vert)
+        qm, qdm, accm, posm, quatm, linm, angm, tipsm, kneesm = _synth_half(g, True, h, init_q, t.goal_quaternions[h:], 0.6 if vert else 0.5, vert)
         rl, rm = t.robot_locomotion, t.robot_manipulation
         rl.joint_positions, rl.joint_velocities, rl.joint_accelerations, rl.tip_positions, rl.knee_positions = ql, qdl, accl, tipsl, kneesl
         rl.base_positions, rl.base_quaternions, rl.base_linear_velocities, rl.base_angular_velocities = posl, quatl, linl, angl
@@ -660,7 +668,7 @@ def main():
         print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "states", "rew", "extras")},
               "resets/step", d["reset_buf"].sum(1)[:8], "max consec", d["consecutive_successes"].max(),
               "bonus steps", int((d["rew"] > 300).sum()))
-    for kind in ("cotrain", "cotrain_pc"):
+    for kind in ("cotrain", "cotrain_pc", "cotrain_v"):
         d = gen_cotrain(kind)
         np.savez_compressed(os.path.join(OUT, f"task_{kind}.npz"), **d)
         print(kind, {k: v.shape for k, v in d.items() if k in ("obs", "rew", "extras")}, "resets/step", d["reset_buf"].sum(1)[:8],
