@@ -331,7 +331,9 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
 #pragma unroll
       for (int j = 0; j < NC; j++) {
         const int tgt = gnn_node(WAVE, j);
-        h[j][0] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; h[j][1] = h[j][0];
+        // max_e ELU(y_e + b) = ELU(max_e y_e + b): ELU and the bias add are monotonic, so the activation is applied once per target node
+        // instead of once per incoming edge (the VALU work of a wavefront is not hidden behind its own MFMAs -- tools/microbench/mfma_chains.hip)
+        f32x4 m0 = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, m1 = m0;
 #pragma unroll
         for (int k = 0; k < gnn_nin(tgt); k++) {
           const int src = gnn_in(tgt, k);
@@ -344,11 +346,10 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], z, acc1, 0, 0, 0);
           }
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            h[j][0][i] = fmaxf(h[j][0][i], elu(acc0[i] + bias2[0][i]));
-            h[j][1][i] = fmaxf(h[j][1][i], elu(acc1[i] + bias2[1][i]));
-          }
+          for (int i = 0; i < 4; i++) { m0[i] = fmaxf(m0[i], acc0[i]); m1[i] = fmaxf(m1[i], acc1[i]); }
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { h[j][0][i] = elu(m0[i] + bias2[0][i]); h[j][1][i] = elu(m1[i] + bias2[1][i]); }
       }
     }
     lds_barrier();       // every wavefront is done reading sPQ before the next layer overwrites it
