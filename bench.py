@@ -11,6 +11,9 @@ resident in HBM before the timed region.  N > 1 = weak scaling: every rank owns 
 (the PPO rollout length, skrl_ppo_locomotion.py:86) the ranks all-gather a (2, 48, N_local) fp32 payload --
 the size of the rollout's returns + advantages -- over RCCL, inside the timed region.
 
+Rank 0 also reports, outside the timed region: the zero-action protocol of SURVEY 8(d) and the same envs with the reference's MLP
+policy in the loop (BASELINE config 2 names one): 48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -160,6 +163,21 @@ def main():
         torch.cuda.synchronize(dev); tz = time.perf_counter()
         for _ in range(nz): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
         torch.cuda.synchronize(dev); zero_rate = N * nz / (time.perf_counter() - tz) if nz else None
+        # BASELINE config 2 names an MLP policy: the same envs with the reference's 64-256-128-64 MLP (random init, seed 42) in the loop --
+        # 48-step rollouts (forward on fp32 MFMA -> gaussian sampling -> step) as one persistent kernel; rank 0, untimed region
+        mlp_rate = None
+        if not args.timed_only:
+            from locomanipulationrl_amd.lib import POLICY_MLP, Rollout
+            from locomanipulationrl_amd.policies.mlp_model import SharedMLP, pack_mlp_params
+            torch.manual_seed(42)
+            pol = SharedMLP().to(dev); packed = pack_mlp_params(pol, None, None).to(dev)
+            ro = Rollout(eng, POLICY_MLP, packed, torch.full((12,), -0.5, device=dev), ROLLOUT, noise_seed=42)
+            eng.step(zact, None, ro.obs[0])
+            for _ in range(3): ro.run("auto"); ro.obs[0].copy_(ro.obs[ROLLOUT])
+            torch.cuda.synchronize(dev); tr = time.perf_counter()
+            for _ in range(20): ro.run("auto"); ro.obs[0].copy_(ro.obs[ROLLOUT])
+            torch.cuda.synchronize(dev); mlp_rate = N * ROLLOUT * 20 / (time.perf_counter() - tr)
+            ro.close()
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -167,7 +185,8 @@ def main():
             "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
                                    "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
                        "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
-                       "zero_action_env_steps_per_s_rank0": zero_rate, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
+                       "zero_action_env_steps_per_s_rank0": zero_rate,
+                       "mlp_policy_in_loop_env_steps_per_s_rank0": mlp_rate, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_step", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
