@@ -20,7 +20,6 @@ from __future__ import annotations
 from dataclasses import dataclass, field, replace
 from typing import List
 
-import numpy as np
 
 MODE_LOCO = 0    # free base on a ground plane
 MODE_MANI = 1    # fixed (inverted) base + free plate
