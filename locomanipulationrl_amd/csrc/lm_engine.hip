@@ -1563,8 +1563,8 @@ int lm_set_seed(lm_engine* h, uint32_t seed) { if (!h) return fail(LM_EINVAL, "l
 // (lm_internal.h) the persistent rollout launch used by lm_rollout_run (lm_policy.hip)
 int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStream_t s) {
   if (!h || !R.params || !R.log_std || !R.obs || !R.actions || !R.logp || !R.values || !R.rewards || !R.dones || !R.acc_steps || R.T <= 0) return -1;
-  if (h->dr_enabled || R.nobs != h->num_obs) return -1;
-  if (!on_device(h)) return -1;
+  if (h->dr_enabled || R.nobs != h->num_obs) return fail(-1, "persistent rollout: domain-randomised engines and foreign observation widths run through the graph mode");
+  if (!on_device(h)) return fail(-1, "persistent rollout: the calling thread's current device is not the engine's device");
   StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   RolloutDev D; D.params = R.params; D.log_std = R.log_std; D.obs = R.obs; D.actions = R.actions; D.logp = R.logp; D.values = R.values;
   D.rewards = R.rewards; D.dones = R.dones; D.acc_steps = R.acc_steps; D.T = R.T; D.noise_seed = R.noise_seed;
@@ -1580,3 +1580,5 @@ int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs) {
   if (!h || h->dr_enabled || nobs != h->num_obs) return 0;
   return (policy == LM_POLICY_MLP && (nobs == 64 || nobs == LM_MAX_OBS)) || (policy == LM_POLICY_GNN && nobs == 64);
 }
+
+int lm_internal_fail(int code, const char* msg) { return fail(code, msg); }

@@ -18,3 +18,5 @@ struct LmRolloutArgs {
 int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStream_t s);
 // 1 when lm_internal_rollout can run this engine / policy / observation width
 int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs);
+// records a message for lm_last_error() (thread-local, lm_engine.hip) and returns `code`
+int lm_internal_fail(int code, const char* msg);

@@ -114,35 +114,35 @@ static int rollout_enqueue(lm_rollout* r, hipStream_t s) {
 }
 
 int lm_sample_actions(const float* mean, const float* log_std, const int64_t* cnt, int n_envs, uint32_t seed, float* actions, float* logp, void* stream) {
-  if (!mean || !log_std || !cnt || !actions || !logp || n_envs <= 0) return -1;
+  if (!mean || !log_std || !cnt || !actions || !logp || n_envs <= 0) return lm_internal_fail(-1, "lm_sample_actions: null argument or n_envs <= 0");
   hipLaunchKernelGGL(k_sample_actions, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, log_std, cnt, n_envs, seed, actions, logp);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int lm_rollout_create(lm_rollout** out, lm_engine* env, int policy, const float* policy_params, const float* log_std, int T, uint32_t noise_seed,
                       float* obs, float* actions, float* logp, float* values, float* rewards, int64_t* dones, float* extras) {
-  if (!out || !env || !policy_params || !log_std || !obs || !actions || !logp || !values || !rewards || !dones || T <= 0) return -1;
-  if (policy != LM_POLICY_MLP && policy != LM_POLICY_GNN) return -1;
+  if (!out || !env || !policy_params || !log_std || !obs || !actions || !logp || !values || !rewards || !dones || T <= 0) return lm_internal_fail(-1, "lm_rollout_create: null argument or T <= 0");
+  if (policy != LM_POLICY_MLP && policy != LM_POLICY_GNN) return lm_internal_fail(-1, "lm_rollout_create: policy must be LM_POLICY_MLP or LM_POLICY_GNN");
   const int nobs = lm_num_obs(env);
-  if (nobs != 64 && !(nobs == 88 && policy == LM_POLICY_MLP)) return -1;      // the GNN reads the 64-wide layout; the MLP also the 88-wide one
+  if (nobs != 64 && !(nobs == 88 && policy == LM_POLICY_MLP)) return lm_internal_fail(-1, "lm_rollout_create: the GNN needs 64-wide observations (the MLP takes 64 or 88)");      // the GNN reads the 64-wide layout; the MLP also the 88-wide one
   lm_rollout* r = new (std::nothrow) lm_rollout();
-  if (!r) return -3;
+  if (!r) return lm_internal_fail(-3, "lm_rollout_create: host allocation failed");
   r->env = env; r->policy = policy; r->T = T; r->N = lm_num_envs(env); r->nobs = nobs; r->seed = noise_seed;
   r->params = policy_params; r->log_std = log_std; r->obs = obs; r->actions = actions; r->logp = logp; r->values = values;
   r->rewards = rewards; r->dones = dones; r->extras = extras; r->exec = nullptr; r->exec_stream = nullptr;
   r->cnt = (const int64_t*)lm_ptr(env, LM_PTR_CNT);
-  if (hipMalloc((void**)&r->mean_tmp, (size_t)r->N * 12 * sizeof(float)) != hipSuccess) { delete r; return -2; }
+  if (hipMalloc((void**)&r->mean_tmp, (size_t)r->N * 12 * sizeof(float)) != hipSuccess) { delete r; return lm_internal_fail(-2, "lm_rollout_create: hipMalloc failed"); }
   r->acc_steps = nullptr;
   { int dev = 0, cus = 0; r->n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? cus : 0; }
   r->persistent_ok = lm_internal_rollout_supported(env, policy, nobs) != 0;
   if (hipMalloc((void**)&r->acc_steps, (size_t)T * 16 * sizeof(long long)) != hipSuccess ||
-      hipMemset(r->acc_steps, 0, (size_t)T * 16 * sizeof(long long)) != hipSuccess) { (void)hipFree(r->mean_tmp); if (r->acc_steps) (void)hipFree(r->acc_steps); delete r; return -2; }
+      hipMemset(r->acc_steps, 0, (size_t)T * 16 * sizeof(long long)) != hipSuccess) { (void)hipFree(r->mean_tmp); if (r->acc_steps) (void)hipFree(r->acc_steps); delete r; return lm_internal_fail(-2, "lm_rollout_create: hipMalloc / hipMemset failed"); }
   *out = r;
   return 0;
 }
 
 int lm_rollout_run(lm_rollout* r, int use_graph, void* stream) {
-  if (!r) return -1;
+  if (!r) return lm_internal_fail(-1, "lm_rollout_run: null plan");
   hipStream_t s = (hipStream_t)stream;
   if (use_graph == LM_ROLLOUT_AUTO)      // a persistent block holds a whole CU (512 registers per lane): one resident generation of blocks, or the graph
     use_graph = (r->persistent_ok && (r->N + 15) / 16 <= r->n_cu) ? LM_ROLLOUT_PERSISTENT : LM_ROLLOUT_GRAPH;
@@ -158,17 +158,17 @@ int lm_rollout_run(lm_rollout* r, int use_graph, void* stream) {
     hipGraph_t g = nullptr;
     hipStream_t cs = s;
     bool own = false;
-    if (cs == nullptr) { if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return -2; own = true; }   // the legacy stream cannot capture
-    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { if (own) (void)hipStreamDestroy(cs); return -2; }
+    if (cs == nullptr) { if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return lm_internal_fail(-2, "lm_rollout_run: hipStreamCreate failed"); own = true; }   // the legacy stream cannot capture
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { if (own) (void)hipStreamDestroy(cs); return lm_internal_fail(-2, "lm_rollout_run: stream capture could not begin (is the stream already capturing?)"); }
     int rc = rollout_enqueue(r, cs);
     hipError_t e = hipStreamEndCapture(cs, &g);
     if (own) (void)hipStreamDestroy(cs);
-    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return rc ? rc : -2; }
+    if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return lm_internal_fail(rc ? rc : -2, "lm_rollout_run: capturing the rollout failed"); }
     e = hipGraphInstantiate(&r->exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { r->exec = nullptr; return -2; }
+    if (e != hipSuccess) { r->exec = nullptr; return lm_internal_fail(-2, "lm_rollout_run: hipGraphInstantiate failed"); }
   }
-  return hipGraphLaunch(r->exec, s) == hipSuccess ? 0 : -2;
+  return hipGraphLaunch(r->exec, s) == hipSuccess ? 0 : lm_internal_fail(-2, "lm_rollout_run: hipGraphLaunch failed");
 }
 
 int lm_rollout_destroy(lm_rollout* r) {

@@ -76,5 +76,5 @@ def test_argument_validation_without_gpu(so):
     # policy / rollout entry points
     assert so.lm_mlp_param_count_obs(64) == so.lm_mlp_param_count() and so.lm_mlp_param_count_obs(88) > so.lm_mlp_param_count() and so.lm_mlp_param_count_obs(70) == -1
     assert so.lm_rollout_create(None, None, 0, None, None, 0, 0, None, None, None, None, None, None, None) == -1
-    assert so.lm_rollout_run(None, 1, None) == -1 and so.lm_rollout_destroy(None) == 0
+    assert so.lm_rollout_run(None, 1, None) == -1 and b"lm_rollout_run" in so.lm_last_error() and so.lm_rollout_destroy(None) == 0
     assert so.lm_sample_actions(None, None, None, 0, 0, None, None, None) == -1
