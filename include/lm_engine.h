@@ -40,7 +40,7 @@ extern "C" {
 #define LM_NUM_ACTIONS 12
 #define LM_NUM_EXTRAS 13  /* 7 reward-term means, success_rate, success_rate of task 0 / task 1 (co-train),
                              custom-controller means: mechanical_power, position_target_error, rot_dist_decreasing */
-#define LM_TABLE_FLOATS 486  /* 10 hub + 4 x 119 limb (RobotModel.packed_table) */
+#define LM_TABLE_FLOATS 502  /* 10 hub + 4 x 123 limb (RobotModel.packed_table) */
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
  * sources in the reference are cited there. */

@@ -25,7 +25,7 @@
 #include "lm_internal.h"
 
 #define HUB_FLOATS 10
-#define LIMB_STRIDE 119
+#define LIMB_STRIDE 123      // 5 joints x 13, 5 inertias x 10, tip (3), foot-sphere centre (3), foot body flag, pad
 #define ENVS_PER_WAVE 16
 
 // state rows
@@ -182,9 +182,11 @@ struct LimbDyn {
   float hq[3];            // limb bias
   SV fcs;                 // limb bias wrench on the hub
   SI Isc;                 // limb composite inertia
-  SV j31, j32;            // motion of link3 per unit rate of (q2, q3); per unit q1 it is s1
-  V3 x;                   // tip point (hub coords)
+  SV j31, j32;            // motion of the foot's body (link3, or link2 on a right-hand module) per unit rate of (q2, q3); per unit q1 it is s1
+  V3 x;                   // centre of the foot sphere (hub coords)
 };
+LM_DEV V3 sel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+LM_DEV SV sel(bool c, SV a, SV b) { return sv(sel(c, a.w, b.w), sel(c, a.v, b.v)); }
 
 LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], SV v0, SV avp0, LimbDyn& D) {
   SI Is = place_inertia(tl + 65, K.Rs, K.os), I4 = place_inertia(tl + 75, K.R4, K.o4), I3 = place_inertia(tl + 85, K.R3, K.o3);
@@ -217,8 +219,13 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
   float gg = g1 * g1 * (Hp1p1 + Hp2p2);
   D.H[0] = H11; D.H[1] = H12 + g1 * (H1p1 - H1p2); D.H[2] = H13 - g1 * (H1p1 - H1p2);
   D.H[3] = H22 + 2.0f * g1 * H2p1 + gg; D.H[4] = -g1 * (H2p1 + H3p2) - gg; D.H[5] = H33 + 2.0f * g1 * H3p2 + gg;
-  D.j31 = fma6(g1, K.sp1, K.s2); D.j32 = (-g1) * K.sp1;
-  D.x = K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117]));
+  // foot collider = the hemispherical end of the long distal link (robot_model.py FOOT_*): link3 (chain dof2 -> p1 = +g(D)) on a left-hand
+  // module, link2 (chain dof3 -> p2 = -g(D)) on a right-hand one
+  const bool on2 = tl[121] != 0.f;
+  const V3 off = v3(tl[118], tl[119], tl[120]);
+  D.j31 = sel(on2, (-g1) * K.sp2, fma6(g1, K.sp1, K.s2));
+  D.j32 = sel(on2, fma6(g1, K.sp2, K.s3), (-g1) * K.sp1);
+  D.x = sel(on2, K.o2 + mul(K.R2, off), K.o3 + mul(K.R3, off));
 }
 
 // Projected Gauss-Seidel over the 4 tip contacts of one env (rows n, t1, t2 per contact, limb order).
@@ -367,10 +374,11 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       C1 = rsqrtf(fmaxf(1.0f - C0.x * C0.x, 1.0e-12f)) * v3(1.0f - C0.x * C0.x, -C0.x * C0.y, -C0.x * C0.z);
       C2 = cross(C0, C1);
       phi = pb.z + dot(C0, D.x) - P->tip_radius;
+      D.x = fma3(-P->tip_radius, C0, D.x);      // from here on: the contact point on the sphere's surface (Jacobians are taken there)
     } else {
       V3 xw = pb + mul(Rb, D.x);
-      V3 y0 = mulT(Rf, xw - F.p);
-      V3 y = y0 - v3(P->plate_center[0], P->plate_center[1], P->plate_center[2]);
+      V3 yc = mulT(Rf, xw - F.p);                // sphere centre, plate coordinates
+      V3 y = yc - v3(P->plate_center[0], P->plate_center[1], P->plate_center[2]);
       // contact face = the slab face on the robot's side of the plate (robust to deep initial overlap)
       float sg = (mulT(Rf, pb - F.p).z - P->plate_center[2] >= 0.f) ? 1.f : -1.f;
       phi = sg * y.z - P->plate_half[2] - P->tip_radius;
@@ -378,6 +386,8 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       // contact axes in plate coords: n=(0,0,sg) t1=(1,0,0) t2=(0,sg,0); in hub coords: Rb^T Rf axis
       M3 Mrp = mulTA(Rb, Rf);
       C0 = sg * Mrp.c2; C1 = Mrp.c0; C2 = sg * Mrp.c1;
+      D.x = fma3(-P->tip_radius, C0, D.x);      // the contact point on the sphere's surface, hub coordinates ...
+      V3 y0 = v3(yc.x, yc.y, yc.z - sg * P->tip_radius);      // ... and plate coordinates
       V3 a0 = v3(0, 0, sg), a1 = v3(1, 0, 0), a2 = v3(0, sg, 0);
       SV Tp0 = sv(-cross(y0, a0), -a0), Tp1 = sv(-cross(y0, a1), -a1), Tp2 = sv(-cross(y0, a2), -a2);
       // plate free motion

@@ -10,10 +10,16 @@ Values and where they come from in the reference:
   vertical deltas
       tasks/quadruped_pose_control_tasks/quadruped_pose_control_vertical.py:84-87,123-126
 
-Contact parameters (mu, tip_radius, baumgarte, max_depen_vel, pgs_iters) belong to THIS engine's
+Contact parameters (mu, baumgarte, max_depen_vel, pgs_iters) belong to THIS engine's
 contact model; the reference delegates contact to PhysX (TGS, 16+2
 iterations, contact_offset 0.005, max depenetration velocity 100 -- YAML :41-50) whose
-algorithm is not reproducible here.
+algorithm is not reproducible here.  Two values were moved in round 2 on the evidence of the
+reference's recorded PhysX joint trajectories (tests/golden/npy_traj.npz):
+  tip_radius 0.005: the foot is the 5 mm hemisphere that ends the long distal link's collision mesh
+  tau_max = max effort / dt: the simulator the reference ran on (Isaac Sim 2022.2 / PhysX 5.1) reads an articulation drive's
+      maxForce as an IMPULSE limit per physics step unless PxArticulationFlag::eDRIVE_LIMITS_ARE_FORCES is raised, so
+      `set_max_efforts(1.5)` (robot.py:347-355) bounds the drive at 1.5 N m s per 0.0083 s step = 180.7 N m, i.e. not at all
+      in practice; with a 1.5 N m torque clamp the recorded joint motions are infeasible for this robot (section 2's table).
 """
 from __future__ import annotations
 
@@ -60,10 +66,10 @@ class EngineParams:
     pgs_iters: int = 8
     gravity: float = 9.81
     kd: float = 100.0
-    tau_max: float = 1.5
+    tau_max: float = 1.5 / 0.0083       # velocity-drive tasks: max effort 1.5 read as an impulse limit per step (see above); PD families: 1.5 N m
     act_scale: float = 3.0
     mu: float = 1.0
-    tip_radius: float = 0.002
+    tip_radius: float = 0.005
     baumgarte: float = 0.2
     max_depen_vel: float = 1.0
     max_joint_vel: float = 7.853981633974483     # 450 deg/s: physxJoint:maxJointVelocity set by Design/Scripts/config_module_joints.py:11,61-69

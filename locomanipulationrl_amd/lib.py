@@ -16,7 +16,7 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.environ.get("LM_ENGINE_SO", os.path.join(_CSRC, "liblm_engine.so"))     # override: kernel experiments only
 
-STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS, TERM_ROWS, READBACK = 115, 6, 64, 93, 12, 13, 486, 11, 99
+STATE_ROWS, CNT_ROWS, NUM_OBS, NUM_STATES, NUM_ACTIONS, NUM_EXTRAS, TABLE_FLOATS, TERM_ROWS, READBACK = 115, 6, 64, 93, 12, 13, 502, 11, 99
 PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_STATS, PTR_TERMS, PTR_DR_CNT, PTR_DR_PHYS = range(10)
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
@@ -105,7 +105,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     src = os.path.join(_CSRC, "lm_engine.hip")
     src2 = os.path.join(_CSRC, "lm_policy.hip")
     inc = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include")
-    deps = [src, src2, os.path.join(_CSRC, "lm_math.h"), os.path.join(_CSRC, "lm_rng.h"), os.path.join(inc, "lm_engine.h"), os.path.join(inc, "lm_policy.h")]
+    import glob
+    deps = sorted(glob.glob(os.path.join(_CSRC, "*.hip")) + glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(inc, "*.h")))      # every source the .so is built from
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"

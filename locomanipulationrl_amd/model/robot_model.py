@@ -40,8 +40,19 @@ LIMB_PARENT = [-1, 0, 1, 0, 3]
 LIMB_JOINT_SUFFIX = ["dof1", "dof2", "link4_to_link3", "dof3", "link1_to_link2"]
 
 # floats per limb in the packed kernel table
-LIMB_STRIDE = 5 * 13 + 5 * 10 + 3 + 1     # 5 joints (R9,p3,sign) + 5 inertias (m,c3,I6) + tip3 + pad = 119
+LIMB_STRIDE = 5 * 13 + 5 * 10 + 3 + 3 + 1 + 1     # 5 joints (R9,p3,sign) + 5 inertias (m,c3,I6) + tip3 + foot centre3 + foot body flag + pad = 123
 HUB_FLOATS = 10
+
+# Foot collider.  The reference keeps the convex hulls of link1-4 as colliders and disables the tip bearings
+# (Design/Scripts/setup_collisions.py:3-10); the only part of a limb that can reach the ground / the plate before the task's knee
+# and corner resets fire is the far end of the LONG distal link: link3 on a left-hand module, link2_right on a right-hand one
+# (Design/RobotURDF/module/overconstrained_module.xacro:129-143,273-302).  Its collision mesh
+# (Design/RobotURDF/mesh/collision/overconstrained/link3.obj, link2_right.obj; mm) ends in an exact hemisphere: the 121 hull vertices
+# with y < -122.5 mm fit a sphere of radius 5.000 mm about (+-4.243, -122.0, -5.243) mm with a residual of 5e-7 mm
+# (tests/golden/foot_hull.npz, tests/test_model.py) - the fingertip_frame the task reads back is that sphere's apex.
+FOOT_RADIUS = 0.005
+FOOT_CENTRE_LEFT = (0.004243, -0.122, -0.005243)       # in the link3 frame
+FOOT_CENTRE_RIGHT = (-0.004243, -0.122, -0.005243)     # in the link2_right frame
 
 
 def closure_g(D):
@@ -78,6 +89,8 @@ class RobotModel:
     tip_off: np.ndarray         # (4,3)
     knee_body: np.ndarray       # (8,)
     limb_body_index: np.ndarray  # (4,5) generic body index of each limb body
+    contact_body: np.ndarray    # (4,) body carrying the foot sphere (the limb's link3, or link2 on a right-hand module)
+    contact_off: np.ndarray     # (4,3) sphere centre in that body's frame
     meta: Dict = field(default_factory=dict)
 
     @property
@@ -120,6 +133,11 @@ class RobotModel:
         poses = self.fk(q12, base_R, base_p, tree_angles)
         return np.stack([poses[b][0] @ self.tip_off[i] + poses[b][1] for i, b in enumerate(self.tip_body)])
 
+    def foot_centres(self, q12, base_R=None, base_p=None, tree_angles=None):
+        """Centres of the four foot spheres (the colliders; the tips above are the frames the task reads)."""
+        poses = self.fk(q12, base_R, base_p, tree_angles)
+        return np.stack([poses[b][0] @ self.contact_off[i] + poses[b][1] for i, b in enumerate(self.contact_body)])
+
     def knee_positions(self, q12, base_R=None, base_p=None):
         poses = self.fk(q12, base_R, base_p)
         return np.stack([poses[b][1] for b in self.knee_body])
@@ -130,7 +148,8 @@ class RobotModel:
 
         Per limb: 5 joints in LIMB_JOINT order, each (R row-major 9, p 3, axis sign 1) where R,p map the
         parent body frame to the joint frame at angle 0; 5 body inertias in LIMB_BODIES order, each
-        (m, com3, I6); tip offset in the link3 frame (3); 1 pad.
+        (m, com3, I6); tip offset in the link3 frame (3); foot-sphere centre in its body's frame (3); foot body flag (0 = the limb's
+        link3, 1 = its link2); 1 pad.
         """
         out = np.zeros(HUB_FLOATS + 4 * LIMB_STRIDE, dtype=np.float64)
 
@@ -153,6 +172,10 @@ class RobotModel:
                 k = int(self.limb_body_index[l, j])
                 out[o + 65 + 10 * j: o + 65 + 10 * j + 10] = pack_inertia(k)
             out[o + 115: o + 118] = self.tip_off[l]
+            out[o + 118: o + 121] = self.contact_off[l]
+            cb = int(self.contact_body[l])
+            assert cb in (int(self.limb_body_index[l, 2]), int(self.limb_body_index[l, 4])), "the foot sphere rides on link3 or link2"
+            out[o + 121] = 0.0 if cb == int(self.limb_body_index[l, 2]) else 1.0
         return out.astype(np.float32)
 
     # ------------------------------------------------------------------ (de)serialisation
@@ -165,7 +188,7 @@ class RobotModel:
     @staticmethod
     def from_json(text: str) -> "RobotModel":
         d = json.loads(text)
-        ints = {"parent", "dof", "clos_p", "clos_a", "clos_b", "tip_body", "knee_body", "limb_body_index"}
+        ints = {"parent", "dof", "clos_p", "clos_a", "clos_b", "tip_body", "knee_body", "limb_body_index", "contact_body"}
         kw = {}
         for k, v in d.items():
             if isinstance(v, list) and k not in ("body_names",):
@@ -203,7 +226,7 @@ def compile_tree(tree: Tree, name: str) -> RobotModel:
             f"unexpected limb topology for {mod}"
         for s, pd in ((+1.0, 12 + 2 * l), (-1.0, 13 + 2 * l)):
             clos_p.append(pd); clos_a.append(driven_dof_index(l, 2)); clos_b.append(driven_dof_index(l, 3)); clos_s.append(s)
-    tip_body, tip_off, knee_body = [], [], []
+    tip_body, tip_off, knee_body, contact_body, contact_off = [], [], [], [], []
     for l, mod in enumerate(MODULES):
         tips = [n for n in tree.link_to_body if n.startswith(mod) and n.endswith("fingertip_frame")]
         assert len(tips) == 1
@@ -212,6 +235,10 @@ def compile_tree(tree: Tree, name: str) -> RobotModel:
         tip_body.append(bi); tip_off.append(p)
         # knee view = origins of link2*/link3* (robot.py:145)
         knee_body += [int(limb_body_index[l, 4]), int(limb_body_index[l, 2])]
+        # foot sphere: on the long distal link (see FOOT_* above); a right-hand module names its links *_right
+        right = tree.bodies[int(limb_body_index[l, 2])].name.endswith("_right")
+        contact_body.append(int(limb_body_index[l, 4 if right else 2]))
+        contact_off.append(np.array(FOOT_CENTRE_RIGHT if right else FOOT_CENTRE_LEFT, dtype=np.float64))
     return RobotModel(
         name=name,
         parent=np.array([b.parent for b in tree.bodies], dtype=np.int64), dof=dof,
@@ -224,7 +251,7 @@ def compile_tree(tree: Tree, name: str) -> RobotModel:
         body_names=[b.name for b in tree.bodies],
         clos_p=np.array(clos_p), clos_a=np.array(clos_a), clos_b=np.array(clos_b), clos_s=np.array(clos_s),
         tip_body=np.array(tip_body), tip_off=np.stack(tip_off), knee_body=np.array(knee_body),
-        limb_body_index=limb_body_index, meta={"source": name},
+        limb_body_index=limb_body_index, contact_body=np.array(contact_body), contact_off=np.stack(contact_off), meta={"source": name},
     )
 
 

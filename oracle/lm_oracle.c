@@ -175,8 +175,9 @@ void lmo_fk(const lmo_model* m, const lmo_params* p, const real* phys, real* tip
  */
 typedef struct {
   real M[NU][NU], h[NU];
-  real tip[4][3];          /* world tip points */
-  real Jt[4][3][NU];       /* world-axes linear Jacobian of tip points wrt u (robot side) */
+  real tip[4][3];          /* world centres of the foot spheres */
+  real cpt[4][3];          /* world contact points = centre - tip_radius * n (on the sphere's surface) */
+  real Jt[4][3][NU];       /* world-axes linear Jacobian of the contact points wrt u (robot side) */
   real R0[9], p0[3];       /* robot base pose */
   real Rf[9], pf[3];       /* free body pose (= base in mode 0, plate in mode 1) */
 } dyn_t;
@@ -250,13 +251,18 @@ static void dyn_compute(const lmo_model* m, const lmo_params* p, const real* phy
   for (int a=0;a<NU;a++) for (int b=0;b<a;b++) D->M[a][b]=D->M[b][a];
   /* tips */
   for (int i=0;i<4;i++) {
-    int tb=m->tip_body[i]; real off[3], t[3]; for (int j=0;j<3;j++) off[j]=(real)m->tip_off[i][j];
+    int tb=m->contact_body[i]; real off[3], t[3]; for (int j=0;j<3;j++) off[j]=(real)m->contact_off[i][j];
     m3v(K.Rw[tb], off, t); for (int j=0;j<3;j++) D->tip[i][j]=K.ow[tb][j]+t[j];
+    /* contact normal (from the surface towards the sphere): world z on the ground; the plate's face normal on the robot's side */
+    { real n[3]={0,0,1};
+      if (!floating) { real db[3], yb[3]; for (int a=0;a<3;a++) db[a]=D->p0[a]-D->pf[a]; m3Tv(D->Rf, db, yb);
+        real sgn=(yb[2]-(real)p->plate_center[2]>=0)?1:-1; real ez[3]={0,0,sgn}; m3v(D->Rf, ez, n); }
+      for (int a=0;a<3;a++) D->cpt[i][a]=D->tip[i][a]-(real)p->tip_radius*n[a]; }
     real JLt[3][LMO_NTREE]; memset(JLt,0,sizeof(JLt)); memset(D->Jt[i],0,sizeof(D->Jt[i]));
-    for (int j=tb; m->parent[j]>=0; j=m->parent[j]) { real r[3], tt[3]; for (int a=0;a<3;a++) r[a]=D->tip[i][a]-K.ow[j][a];
+    for (int j=tb; m->parent[j]>=0; j=m->parent[j]) { real r[3], tt[3]; for (int a=0;a<3;a++) r[a]=D->cpt[i][a]-K.ow[j][a];
       cross(K.zw[j], r, tt); for (int a=0;a<3;a++) JLt[a][m->dof[j]]=tt[a]; }
     for (int a=0;a<3;a++) for (int c=0;c<LMO_NQ;c++) { real s=0; for (int tt=0;tt<LMO_NTREE;tt++) s+=JLt[a][tt]*K.G[tt][c]; D->Jt[i][a][6+c]=s; }
-    if (floating) { real r[3]; for (int a=0;a<3;a++) r[a]=D->tip[i][a]-D->p0[a];
+    if (floating) { real r[3]; for (int a=0;a<3;a++) r[a]=D->cpt[i][a]-D->p0[a];
       for (int c=0;c<3;c++) { real col[3]={D->R0[c],D->R0[3+c],D->R0[6+c]}, tt[3]; cross(col, r, tt);
         for (int a=0;a<3;a++) { D->Jt[i][a][c]=tt[a]; D->Jt[i][a][3+c]=col[a]; } } }
   }
@@ -321,8 +327,12 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
       real hx=D->R0[0], hy=D->R0[3], hn=sqrt(hx*hx+hy*hy); if (hn<(real)1e-6) hn=(real)1e-6;
       n[0]=0;n[1]=0;n[2]=1; t1[0]=hx/hn;t1[1]=hy/hn;t1[2]=0; t2[0]=-t1[1];t2[1]=t1[0];t2[2]=0; phi=D->tip[i][2]-(real)p->tip_radius; }
     else {
-      real d[3], y0[3], y[3]; for (int a=0;a<3;a++) d[a]=D->tip[i][a]-D->pf[a]; m3Tv(D->Rf, d, y0);
-      for (int a=0;a<3;a++) y[a]=y0[a]-(real)p->plate_center[a];
+      real d[3], y0[3], y[3], yc[3];
+      for (int a=0;a<3;a++) d[a]=D->tip[i][a]-D->pf[a];
+      m3Tv(D->Rf, d, yc);                                                                                              /* sphere centre, plate coords */
+      for (int a=0;a<3;a++) d[a]=D->cpt[i][a]-D->pf[a];
+      m3Tv(D->Rf, d, y0);                                                                                              /* contact point, plate coords */
+      for (int a=0;a<3;a++) y[a]=yc[a]-(real)p->plate_center[a];
       /* contact face = the slab face on the robot's side of the plate (robust to deep initial overlap) */
       real db[3], yb[3]; for (int a=0;a<3;a++) db[a]=D->p0[a]-D->pf[a]; m3Tv(D->Rf, db, yb);
       real sgn = (yb[2]-(real)p->plate_center[2]>=0)?1:-1; real ez[3]={0,0,sgn}, ex[3]={1,0,0};

@@ -52,8 +52,12 @@ typedef struct {
   int32_t clos_p[8], clos_a[8], clos_b[8];
   double clos_s[8];
   int32_t tip_body[4];
-  double tip_off[4][3];
+  double tip_off[4][3];          /* fingertip_frame: the point the task layer reads back (robot.py:300-310) */
   int32_t knee_body[8];
+  /* foot collider: the hemispherical end of the long distal link (Design/RobotURDF/mesh/collision/overconstrained/link3.obj,
+     link2_right.obj: exact hemisphere, radius 5 mm, centre 5 mm behind the fingertip frame); radius = lmo_params.tip_radius */
+  int32_t contact_body[4];
+  double contact_off[4][3];      /* sphere centre in the contact body's frame */
 } lmo_model;
 
 #define LMO_DR_CHANNELS 9

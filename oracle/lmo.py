@@ -24,6 +24,7 @@ class LmoModel(C.Structure):
         ("nclos", C.c_int32), ("clos_p", C.c_int32 * 8), ("clos_a", C.c_int32 * 8), ("clos_b", C.c_int32 * 8),
         ("clos_s", C.c_double * 8),
         ("tip_body", C.c_int32 * 4), ("tip_off", (C.c_double * 3) * 4), ("knee_body", C.c_int32 * 8),
+        ("contact_body", C.c_int32 * 4), ("contact_off", (C.c_double * 3) * 4),
     ]
 
 
@@ -95,6 +96,9 @@ def make_model(rm) -> LmoModel:
     _set(m.tip_off, rm.tip_off)
     for i in range(8):
         m.knee_body[i] = int(rm.knee_body[i])
+    for i in range(4):
+        m.contact_body[i] = int(rm.contact_body[i])
+    _set(m.contact_off, rm.contact_off)
     return m
 
 

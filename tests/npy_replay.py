@@ -1,0 +1,96 @@
+"""Replay of the reference's recorded PhysX joint trajectories (tests/golden/npy_traj.npz) -- shared by the CPU (oracle) and GPU (HIP
+engine) tests.  TEST INFRASTRUCTURE.
+
+What the recordings are (RobotLearning/omniisaacgymenvs/tasks/joint_train_locomanipulation/joint_locomanipulation.py:36-46,556-563,
+861-874): the co-training task with its committed FIXED goal (roll 0.2, pitch 0.2, yaw 0.785, :61-66) appends the 12 driven joint positions
+of env 0 of the locomotion half and of the manipulation robot view in every get_observations() call, i.e. one row per control step
+starting with the reset step (zero action), until that half's reset flag is raised; the episode that ends the file is therefore
+recorded up to and including its terminal step.  Scene of that task: class-default joint pose (robot/quadruped_robot.py:45-52),
+locomotion base dropped from z 0.18 (:53), inverted manipulation robot fixed at z 0.5 with the plate dropped from z 0.68 (:139,198).
+
+What can be recovered: PhysX's velocity drive tracks its target within a control period, so the action sequence is
+a_t = clip((q[t+1] - q[t]) / (3.0 rad/s * 0.0332 s), +-1).  Replaying it open loop from the same reset pins the physics of row a7
+(drive + contact + articulated dynamics) against the only simulator-derived numbers the reference holds.
+
+Which goal a file was recorded under is known only for the committed code (0.2, 0.2, 0.785); the three `04roll-*` files carry
+another goal in their name, so orientation statistics are taken from the `mlp_*` files and `test` only.
+"""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+from locomanipulationrl_amd.engine_config import loco_params, mani_params
+
+INIT_Q = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]      # robot/quadruped_robot.py:45-52
+GOAL = [0.2, 0.2, 0.785]                                                                 # joint_locomanipulation.py:61-66
+FULL = 3.0 * 0.0332                                                                      # joint displacement of a saturated action
+
+# the two duplicated recordings (byte-identical arrays) are replayed once
+FILES = ["04roll_loco_from_mani", "04roll_loco_from_scratch", "04roll_mani_from_scratch", "mlp_joint_loco", "mlp_joint_loco_from_mani",
+         "mlp_joint_loco_from_scratch", "mlp_joint_mani", "mlp_joint_mani_from_scratch", "mlp_loco_from_mani", "mlp_mani_from_loco", "test"]
+GOAL_KNOWN = [f for f in FILES if f.startswith("mlp_")]
+
+
+def kind_of(name):
+    return "mani" if "mani" in name.split("from")[0] else "loco"
+
+
+def load():
+    g = np.load(os.path.join(GOLDEN, "npy_traj.npz"))
+    return {k: g[k].astype(np.float64) for k in g.files}
+
+
+def cotrain_params(kind, **kw):
+    """The two parameter blocks of JointLocomanipulation with the committed fixed goal."""
+    if kind == "loco":
+        return loco_params(**{**dict(init_q=list(INIT_Q), init_base_pos=[0, 0, 0.18], goal_lo=GOAL, goal_hi=GOAL), **kw})
+    return mani_params(**{**dict(init_q=list(INIT_Q), fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68], goal_lo=GOAL, goal_hi=GOAL), **kw})
+
+
+def recovered_actions(rec):
+    return np.clip(np.diff(rec, axis=0) / FULL, -1.0, 1.0)
+
+
+def rot_dist(obs_row):
+    return 2.0 * np.arcsin(min(float(np.linalg.norm(obs_row[7:10])), 1.0))
+
+
+def replay(rec, step, servo=False):
+    """step(action (12,)) -> (q (12,), obs (64,), reset flag, goal_reset flag) advances one control step; the first call gets the zero
+    action of VecEnvRLGames.reset().  servo=True steers the joints back onto the recording every step (actions still clipped to +-1)."""
+    T = rec.shape[0]
+    q, obs, rst, _ = step(np.zeros(12))
+    out = dict(T=T, row0_err=float(np.abs(q - rec[0]).max()), rows=[q.copy()], rd=[rot_dist(obs)], done_at=None, goal=0)
+    acts = recovered_actions(rec)
+    derr = []
+    for t in range(T - 1):
+        a = np.clip((rec[t + 1] - q) / FULL, -1, 1) if servo else acts[t]
+        q0 = q
+        q, obs, rst, goal = step(a)
+        out["rows"].append(q.copy()); out["rd"].append(rot_dist(obs)); derr.append((q - q0) - (rec[t + 1] - rec[t]))
+        if rst:
+            out["done_at"], out["goal"] = t + 1, int(goal)
+            break
+    rows = np.array(out["rows"]); derr = np.array(derr); n = len(rows)
+    out.update(rows=rows, rd=np.array(out["rd"]), tracked=float((np.abs(derr) < 1e-3).mean()), qerr=float(np.abs(rows - rec[:n]).max()),
+               early=float(np.abs(derr[:4]).mean() / FULL), succ_row=T - 17)
+    first = np.nonzero(out["rd"] <= 0.15)[0]
+    out["first_succ"] = int(first[0]) if len(first) else None
+    return out
+
+
+def oracle_stepper(robot_model, ep, precision="f64"):
+    from oracle.lmo import Oracle
+    o = Oracle(robot_model, ep, precision)
+    phys, task, cnt = o.new_state(1)
+
+    def step(a):
+        obs, st, rew, terms = o.step(phys, task, cnt, np.asarray(a, dtype=np.float64)[None], seed=0)
+        return phys[0, 13:25].astype(np.float64).copy(), obs[0].astype(np.float64), int(cnt[0, 3]), int(cnt[0, 2])
+    return step
+
+
+def summary_line(name, r):
+    return (f"{name:30s} T-1={r['T'] - 1:3d} row0={r['row0_err']:.4f} tracked={r['tracked']:.3f} qerr={r['qerr']:.3f} early={r['early']:.4f} "
+            f"done_at={r['done_at']}{'G' if r['goal'] else ''} first<=0.15:{r['first_succ']} (PhysX {r['succ_row']}) min rd={r['rd'].min():.3f} last rd={r['rd'][-1]:.3f}")

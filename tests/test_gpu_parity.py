@@ -412,7 +412,8 @@ def test_randomised_env_through_the_wrapper(engine_cls):
         o, r, d, ex = env.step(torch.rand(128, 12, device="cuda", generator=g) * 2 - 1)
     e = env._task.engine
     ph = e.dr_phys.cpu().numpy()
-    assert (ph[:12] >= 0.7 * 1.5 - 1e-6).all() and (ph[:12] <= 0.9 * 1.5 + 1e-6).all()
+    tm = env._task.engine_params()[0].tau_max          # max effort 1.5 read as an impulse limit per step: 1.5 / dt
+    assert abs(tm - 1.5 / 0.0083) < 1e-3 and (ph[:12] >= 0.7 * tm - 1e-3).all() and (ph[:12] <= 0.9 * tm + 1e-3).all()
     assert abs(ph[26].mean() + 9.81) < 0.2 and 0.3 < ph[26].std() < 0.7 and 3.0 < ph[27:30].std() < 7.0
     assert torch.isfinite(o["obs"]).all() and (e.dr_cnt[2] == 6).all()
     env.close()

@@ -94,7 +94,7 @@ def test_step_dr_semantics(robot_model):
         inner = np.abs(act) < 0.9
         d = (used - act)[inner]
         assert 0.005 < d.std() < 0.04 and np.abs(d).max() < 0.12             # sqrt(0.015^2 + 0.01^2) = 0.018
-        assert (phd[:, :12] >= 0.7 * 1.5 - 1e-9).all() and (phd[:, :12] <= 0.9 * 1.5 + 1e-9).all()
+        assert (phd[:, :12] >= 0.7 * ep.tau_max - 1e-9).all() and (phd[:, :12] <= 0.9 * ep.tau_max + 1e-9).all()
         assert (phd[:, 12:24] >= 0.95 * ep.max_joint_vel - 1e-9).all() and (phd[:, 12:24] <= 1.05 * ep.max_joint_vel + 1e-9).all()
         grav.append(phd[:, 24:27].copy()); force.append(phd[:, 27:30].copy())
         assert np.isfinite(obs).all() and np.isfinite(rew).all()

@@ -59,7 +59,8 @@ def test_standing_is_stable(robot_model):
     for _ in range(300):
         o.substep(phys, np.zeros((4, 12)))
     tips, knees = o.fk(phys)
-    assert np.abs(tips[:, :, 2] - ep.tip_radius).max() < 1e-3                      # feet rest on the ground
+    feet = np.stack([robot_model.foot_centres(ph[13:25], quat2mat(ph[3:7]), ph[:3]) for ph in phys])
+    assert np.abs(feet[:, :, 2] - ep.tip_radius).max() < 1e-3                      # the foot spheres rest on the ground
     assert 0.12 < phys[0, 2] < 0.14 and np.abs(phys[:, 7:13]).max() < 0.02        # base settled ~0.131 m
     assert np.abs(phys[:, 13:25] - np.array(ep.init_q)).max() < 0.03               # velocity servo creeps slowly under load
     assert knees[:, :, 2].min() > 0.04 and np.abs(phys[:, 3:7] - [1, 0, 0, 0]).max() < 0.01
@@ -87,9 +88,9 @@ def test_plate_rests_on_inverted_robot(robot_model):
     phys, task, cnt = o.new_state(2); o.reset(phys, task, cnt)
     for _ in range(300):
         o.substep(phys, np.zeros((2, 12)))
-    tips, _ = o.fk(phys)
+    feet = np.stack([robot_model.foot_centres(ph[13:25], quat2mat(ep.fixed_base_quat), np.array(ep.fixed_base_pos)) for ph in phys])
     # flipped plate (quat [0,1,0,0]): its lower world face is plate-frame z = 0.008
-    assert np.abs((phys[:, 39] - 0.008) - (tips[:, :, 2].mean(1) + ep.tip_radius)).max() < 1.5e-3
+    assert np.abs((phys[:, 39] - 0.008) - (feet[:, :, 2].mean(1) + ep.tip_radius)).max() < 1.5e-3
     assert np.abs(phys[:, 44:50]).max() < 0.02 and np.abs(phys[:, 37:39]).max() < 5e-3
 
 
@@ -116,7 +117,7 @@ def test_reference_npy_row0_envelope(robot_model):
 def test_saturated_drive_respects_torque_limit(robot_model):
     """A target far from the joint velocity saturates the drive: the velocity change per sub-step is bounded by
     tau_max * dt / (smallest joint-space inertia), not by the 100 N m s/rad gain."""
-    ep = loco_params(); o = Oracle(robot_model, ep)
+    ep = loco_params(tau_max=1.5); o = Oracle(robot_model, ep)      # a real 1.5 N m clamp (the PD-actuator families; `drive_limits_are_impulses: False`)
     phys, task, cnt = o.new_state(1); o.reset(phys, task, cnt); phys[0, 2] = 5.0
     M, _ = o.dyn_terms(phys[0])
     o.substep(phys, np.full((1, 12), 3.0))
