@@ -11,8 +11,13 @@ resident in HBM before the timed region.  N > 1 = weak scaling: every rank owns 
 (the PPO rollout length, skrl_ppo_locomotion.py:86) the ranks all-gather a (2, 48, N_local) fp32 payload --
 the size of the rollout's returns + advantages -- over RCCL, inside the timed region.
 
-Rank 0 also reports, outside the timed region: the zero-action protocol of SURVEY 8(d) and the same envs with the reference's MLP
-policy in the loop (BASELINE config 2 names one): 48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`).
+Rank 0 also reports, outside the timed region: the same workload through the drop-in boundary itself (`VecEnvRLGames.step`,
+`config.vec_env_step_env_steps_per_s`: fresh output tensors and the extras dict per call, as the reference's wrapper hands them out),
+the zero-action protocol of SURVEY 8(d) and the same envs with the reference's MLP policy in the loop (BASELINE config 2 names one):
+48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts `torch.distributed.run` with N ranks as a child BEFORE
+touching the GPU and exits with its code.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,51 +35,94 @@ ROLLOUT = 48
 BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (460 read + 1028 written)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_v6.json")   # rocprofv3 --pmc passes of this same command (FETCH/WRITE_SIZE, flop counters)
+# rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE / flop counters, tools/profile_round.sh): counters cannot be
+# collected from inside the run, so `roofline.traffic` and `valu.flop_per_env_step` are READ FROM the newest of these files and labelled so
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc_v6.json")]
 
 
-def cpu_baseline(steps: int = 150, envs: int = 4096, params=None):
-    """The CPU oracle (float32 build, OpenMP over envs) timed on this host on a bounded sample of the same workload
-    (params: engine parameters of another task family, default = the headline locomotion task)."""
-    import numpy as np
-    from locomanipulationrl_amd.engine_config import loco_params
-    from locomanipulationrl_amd.model.robot_model import load_model
-    from oracle.lmo import Oracle
-    cores = os.cpu_count() or 1
-    cores = min(cores, 64)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    try:      # a second call in one process: the OpenMP runtime is already up and ignores the environment
+def _omp_threads(n):
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    try:      # a later call in one process: the OpenMP runtime is already up and ignores the environment
         import ctypes
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(n)
     except OSError:
         pass
-    o = Oracle(load_model("quadruped_robot_v2"), params or loco_params(), "f32")
+
+
+def _time_oracle(o, envs, steps, seed=42):
+    import numpy as np
     phys, task, cnt = o.new_state(envs)
-    rng = np.random.default_rng(42)
+    rng = np.random.default_rng(seed)
     acts = rng.uniform(-1, 1, size=(steps + 2, envs, 12)).astype(np.float32)
-    o.step(phys, task, cnt, acts[0], seed=42); o.step(phys, task, cnt, acts[1], seed=42)
+    o.step(phys, task, cnt, acts[0], seed=seed); o.step(phys, task, cnt, acts[1], seed=seed)
     t0 = time.perf_counter()
     for t in range(steps):
-        o.step(phys, task, cnt, acts[2 + t], seed=42)
-    dt = time.perf_counter() - t0
-    out = {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "sample": f"{envs} envs x {steps} steps of the same task on the CPU oracle (fp32 build, OpenMP over envs, {dt:.1f} s); "
-                     "PhysX-CPU itself is unavailable (closed source, not installed)"}
-    try:      # the same oracle on ONE core (SURVEY 8d asks for both)
-        import ctypes
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
-        n1, s1 = 1024, 12
-        p1, t1, c1 = o.new_state(n1)
-        o.step(p1, t1, c1, acts[0][:n1], seed=42)
-        t0 = time.perf_counter()
-        for t in range(s1):
-            o.step(p1, t1, c1, acts[(2 + t) % len(acts)][:n1], seed=42)
-        d1 = time.perf_counter() - t0
-        out["value_1core"] = n1 * s1 / d1
-        out["sample"] += f"; one core: {n1} envs x {s1} steps ({d1:.1f} s)"
-    except OSError:
+        o.step(phys, task, cnt, acts[2 + t], seed=seed)
+    return envs * steps / (time.perf_counter() - t0), time.perf_counter() - t0
+
+
+def cpu_baseline(steps: int = 150, envs: int = 4096):
+    """The CPU oracle (float32 build, OpenMP over envs) timed on this host on bounded samples of the same workloads: every hardware
+    thread this process may use and one core, on BASELINE configs 2 (the headline), 3 and the per-GPU block of config 4."""
+    from locomanipulationrl_amd.engine_config import loco_params, mani_params
+    from locomanipulationrl_amd.model.robot_model import load_model
+    from oracle.lmo import Oracle
+    nproc = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
+    rm = load_model("quadruped_robot_v2")
+    o = Oracle(rm, loco_params(), "f32")
+    # "all host cores" = all this process is ALLOWED to use: the affinity mask can name every hardware thread of the host while the
+    # container's CPU quota is a fraction of it (oversubscribed OpenMP threads are then throttled: 256 threads ran 20x slower than 64 here).
+    # Take the cgroup CPU quota when there is one; otherwise keep the thread count that is fastest on a short probe.
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else max(1, int(-(-int(q) // int(per))))
+    except (OSError, ValueError):
         pass
+    probe = {}
+    if quota is not None:
+        usable = min(quota, affinity)          # a short probe would ride the quota's burst allowance (64 threads probe 3x faster and then run 2x slower)
+    else:
+        for c in sorted({c for c in (8, 16, 32, 64, 128, affinity) if c <= affinity}):
+            _omp_threads(c)
+            probe[c] = _time_oracle(o, 2048, 4)[0]
+        usable = max(probe, key=probe.get)
+    _omp_threads(usable)
+    rate, dt = _time_oracle(o, envs, steps)
+    out = {"value": rate, "unit": "env-steps/s", "cores": usable, "nproc": nproc, "affinity": affinity, "cgroup_cpu_quota": quota, "kind": "port",
+           "thread_probe_env_steps_per_s": {str(k): round(v) for k, v in probe.items()},
+           "sample": f"{envs} envs x {steps} steps of the same task on the CPU oracle (fp32 build, OpenMP over envs, {usable} threads = the CPUs this process "
+                     f"may use; nproc {nproc}, affinity {affinity}, cgroup quota {quota}; {dt:.1f} s); "
+                     "PhysX-CPU itself is unavailable (closed source, not installed)"}
+    om = Oracle(rm, mani_params(), "f32")
+    out["config3_manipulation_4096"] = _time_oracle(om, envs, steps // 2)[0]
+    # config 4's per-GPU block: 2048 locomotion + 2048 manipulation envs (two oracles, timed back to back)
+    cl = __import__("dataclasses").replace
+    lo = Oracle(rm, cl(loco_params(), init_q=[-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92], init_base_pos=[0, 0, 0.18]), "f32")
+    mo = Oracle(rm, cl(mani_params(), init_q=[-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92], fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68]), "f32")
+    ra, rb = _time_oracle(lo, envs // 2, steps // 2)[0], _time_oracle(mo, envs // 2, steps // 2)[0]
+    out["config4_cotrain_block_2048_2048"] = envs / (envs / 2 / ra + envs / 2 / rb)
+    _omp_threads(1)      # the same oracle on ONE core
+    n1, s1 = 1024, 12
+    r1, d1 = _time_oracle(o, n1, s1)
+    out["value_1core"] = r1
+    out["sample"] += f"; one core: {n1} envs x {s1} steps ({d1:.1f} s)"
     return out
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as children of a process that has not touched
+    the GPU (never re-exec a process that has) and hand back their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    cmd += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
+    cmd += ["--timed-only"] if args.timed_only else []
+    return subprocess.call(cmd)
 
 
 def main():
@@ -85,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="skip the event-timing and zero-action legs (counter collection runs: every k_step dispatch is then the timed protocol)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -152,9 +202,11 @@ def main():
         k_ms = sorted(a.elapsed_time(b) for a, b in evs) or [elapsed / args.steps * 1e3]
         k_avg_ms = sum(k_ms) / len(k_ms)
         achieved = BYTES_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e9
-        pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
+        pmc_file = next((f for f in PMC_FILES if os.path.exists(f)), None)
+        pmc = json.load(open(pmc_file)) if pmc_file else None
         traffic = pmc["per_launch"]["hbm_traffic_bytes"] if pmc else None
-        flop_env = pmc["flop_per_env_step"] if pmc else 1.67e5
+        flop_env = pmc["flop_per_env_step"] if pmc else None
+        pmc_src = ("read from " + os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of this command; not collected in this run)") if pmc else None
         value = world * N * args.steps / elapsed
         # second protocol of SURVEY 8(d): zero actions (standing robots, only the 300-step timeout resets); rank 0, untimed region
         zact = torch.zeros(N, 12, device=dev)
@@ -163,6 +215,22 @@ def main():
         torch.cuda.synchronize(dev); tz = time.perf_counter()
         for _ in range(nz): eng.step(zact, None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras)
         torch.cuda.synchronize(dev); zero_rate = N * nz / (time.perf_counter() - tz) if nz else None
+        # the drop-in boundary itself: VecEnvRLGames.step (vec_env_rlgames.py:56-79) on the same workload -- fresh output tensors and the
+        # extras dict per call; rank 0, untimed region
+        vec_rate = None
+        if not args.timed_only:
+            import contextlib, io
+            import locomanipulationrl_amd as lm
+            env = lm.make_env("QuadrupedPoseControl", num_envs=N, seed=42, sim_device=str(dev), rl_device=str(dev))
+            with contextlib.redirect_stdout(io.StringIO()):
+                env.reset()
+            for i in range(200): env.step(pool[i % 64])
+            torch.cuda.synchronize(dev); tv = time.perf_counter()
+            nv = 2000
+            for i in range(nv): obs_d, rw_, rs_, ex_ = env.step(pool[i % 64])
+            torch.cuda.synchronize(dev); vec_rate = N * nv / (time.perf_counter() - tv)
+            assert obs_d["obs"].shape == (N, 64) and "env/success_rate" in ex_
+            env.close()
         # BASELINE config 2 names an MLP policy: the same envs with the reference's 64-256-128-64 MLP (random init, seed 42) in the loop --
         # 48-step rollouts (forward on fp32 MFMA -> gaussian sampling -> step) as one persistent kernel; rank 0, untimed region
         mlp_rate = None
@@ -185,14 +253,16 @@ def main():
             "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
                                    "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
                        "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
+                       "vec_env_step_env_steps_per_s": vec_rate,
                        "zero_action_env_steps_per_s_rank0": zero_rate,
                        "mlp_policy_in_loop_env_steps_per_s_rank0": mlp_rate, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_step", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
+                         "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
-            "valu": {"achieved": flop_env * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flop_env * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64,
-                     "flop_per_env_step": flop_env},
+            "valu": None if flop_env is None else {
+                "achieved": flop_env * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flop_env * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64,
+                "flop_per_env_step": flop_env, "flop_source": pmc_src},
         }
     eng.close()
     if world > 1:

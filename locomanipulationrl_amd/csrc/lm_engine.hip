@@ -25,8 +25,32 @@
 #include "lm_internal.h"
 
 #define HUB_FLOATS 10
-#define LIMB_STRIDE 123      // 5 joints x 13, 5 inertias x 10, tip (3), foot-sphere centre (3), foot body flag, pad
 #define ENVS_PER_WAVE 16
+// Device-side table layout (built from the packed public table by permute_table() in lm_create).  A limb is the shell plus two
+// structurally identical two-link chains, A = link4 -> link3 (joints dof2, p1) and B = link1 -> link2 (joints dof3, p2); the entries
+// of the chains are interleaved (A, B) so that one 8-byte LDS read feeds one packed-fp32 operand (lm_math.h).
+#define PUB_LIMB_STRIDE 123   // public: 5 joints x 13, 5 inertias x 10, tip (3), foot-sphere centre (3), foot body flag, pad
+#define LIMB_STRIDE 124       // device: even, every pair 8-byte aligned
+#define T_J0 0                // shell joint: R (9, row-major), p (3), axis sign
+#define T_P1 14               // 13 pairs: first joints of the chains (dof2 | dof3)
+#define T_P2 40               // 13 pairs: second joints (p1 | p2)
+#define T_I0 66               // shell inertia (m, com 3, I 6)
+#define T_Q1 76               // 10 pairs: link4 | link1
+#define T_Q2 96               // 10 pairs: link3 | link2
+#define T_TIP 116             // fingertip frame on link3
+#define T_FOOT 119            // foot-sphere centre in its body's frame
+#define T_FLAG 122            // 0: the foot rides on link3, 1: on link2
+#define LM_ITAB_FLOATS (HUB_FLOATS + 4 * LIMB_STRIDE)
+static void permute_table(const float* pub, float* dev) {
+  memset(dev, 0, LM_ITAB_FLOATS * sizeof(float));
+  for (int i = 0; i < HUB_FLOATS; i++) dev[i] = pub[i];
+  for (int l = 0; l < 4; l++) {
+    const float* s = pub + HUB_FLOATS + l * PUB_LIMB_STRIDE; float* d = dev + HUB_FLOATS + l * LIMB_STRIDE;
+    for (int k = 0; k < 13; k++) { d[T_J0 + k] = s[k]; d[T_P1 + 2 * k] = s[13 + k]; d[T_P1 + 2 * k + 1] = s[39 + k]; d[T_P2 + 2 * k] = s[26 + k]; d[T_P2 + 2 * k + 1] = s[52 + k]; }
+    for (int k = 0; k < 10; k++) { d[T_I0 + k] = s[65 + k]; d[T_Q1 + 2 * k] = s[75 + k]; d[T_Q1 + 2 * k + 1] = s[95 + k]; d[T_Q2 + 2 * k] = s[85 + k]; d[T_Q2 + 2 * k + 1] = s[105 + k]; }
+    for (int k = 0; k < 7; k++) d[T_TIP + k] = s[115 + k];
+  }
+}
 
 // state rows
 #define R_FB0 0            // base: pos 0..2 quat 3..6 lin 7..9 ang 10..12
@@ -136,28 +160,58 @@ LM_DEV void si_to_66(const SI& I, float A[6][6]) {
 LM_DEV void sv_to_arr(SV a, float* o) { o[0] = a.w.x; o[1] = a.w.y; o[2] = a.w.z; o[3] = a.v.x; o[4] = a.v.y; o[5] = a.v.z; }
 LM_DEV SV arr_to_sv(const float* o) { return sv(v3(o[0], o[1], o[2]), v3(o[3], o[4], o[5])); }
 
-// one joint of the limb tree: parent pose (Rp, op) + table entry (R 9 row-major, p 3, sign) + rotation (c, s)
-LM_DEV void joint_frame(const M3& Rp, V3 op, const float* tj, float c, float s, M3& R, V3& o, V3& z) {
-  M3 A = mul(Rp, load_m3_rowmajor(tj));
+// one joint of the limb tree: parent pose (Rp, op) + table entry (R 9 row-major, p 3, sign) + rotation (c, s); T = float for the shell
+// joint, f2 for a pair of chain joints (table entries interleaved)
+template <class T> LM_DEV M3T<T> load_m3_rowmajor_t(const T* t) {
+  M3T<T> R; R.c0 = v3t<T>(t[0], t[3], t[6]); R.c1 = v3t<T>(t[1], t[4], t[7]); R.c2 = v3t<T>(t[2], t[5], t[8]); return R;
+}
+template <class T> LM_DEV void joint_frame(const M3T<T>& Rp, V3T<T> op, const T* tj, T c, T s, M3T<T>& R, V3T<T>& o, V3T<T>& z) {
+  M3T<T> A = mul(Rp, load_m3_rowmajor_t<T>(tj));
+  T sg = tj[12]; T ss = sg * s;
+  R.c0 = fma3(c, A.c0, ss * A.c1);
+  R.c1 = fma3(c, A.c1, (-ss) * A.c0);
+  R.c2 = A.c2;
+  o = op + mul(Rp, v3t<T>(tj[9], tj[10], tj[11]));
+  z = sg * A.c2;
+}
+// the shell joint hangs on the hub frame itself (identity parent): no parent products
+LM_DEV void joint_frame_root(const float* tj, float c, float s, M3& R, V3& o, V3& z) {
+  M3 A = load_m3_rowmajor_t<float>(tj);
   float sg = tj[12]; float ss = sg * s;
   R.c0 = fma3(c, A.c0, ss * A.c1);
   R.c1 = fma3(c, A.c1, (-ss) * A.c0);
   R.c2 = A.c2;
-  o = op + mul(Rp, v3(tj[9], tj[10], tj[11]));
+  o = v3(tj[9], tj[10], tj[11]);
   z = sg * A.c2;
 }
+// sin/cos of a pair of angles (same polynomial as lm_sincos, both halves in packed instructions where the ISA has them)
+LM_DEV void lm_sincos2(f2 x, f2* s, f2* c) {
+  const f2 kf = mk2(rintf(x.x * 0.636619772367581343f), rintf(x.y * 0.636619772367581343f));
+  const int k0 = (int)kf.x, k1 = (int)kf.y;
+  f2 r = fma_(-kf, sp2(1.57079625129699707031f), x);
+  r = fma_(-kf, sp2(7.54978941586159635335e-8f), r);
+  r = fma_(-kf, sp2(5.39030285815811905290e-15f), r);
+  const f2 z = r * r;
+  const f2 sp = fma_(fma_(fma_(sp2(-1.9515295891e-4f), z, sp2(8.3321608736e-3f)), z, sp2(-1.6666654611e-1f)), z * r, r);
+  const f2 cp = fma_(fma_(fma_(sp2(2.443315711809948e-5f), z, sp2(-1.388731625493765e-3f)), z, sp2(4.166664568298827e-2f)), z * z, fma_(sp2(-0.5f), z, sp2(1.0f)));
+  const float ss0 = (k0 & 1) ? cp.x : sp.x, cc0 = (k0 & 1) ? sp.x : cp.x, ss1 = (k1 & 1) ? cp.y : sp.y, cc1 = (k1 & 1) ? sp.y : cp.y;
+  *s = mk2((k0 & 2) ? -ss0 : ss0, (k1 & 2) ? -ss1 : ss1);
+  *c = mk2(((k0 + 1) & 2) ? -cc0 : cc0, ((k1 + 1) & 2) ? -cc1 : cc1);
+}
 
-// kinematics + dynamics terms of one limb, all in hub ("base") coordinates about the hub origin
+// kinematics + dynamics terms of one limb, all in hub ("base") coordinates about the hub origin.  Pairs hold (chain A | chain B) =
+// (link4 | link1) at the first level and (link3 | link2) at the second.
 struct LimbKin {
-  M3 R3; V3 os, o4, o3, o1, o2;            // frames needed later (tip on link3, knees = o3, o2)
-  SV s1, s2, sp1, s3, sp2;                 // joint axes
+  M3 Rs; V3 os; SV s1;                     // shell
+  M3P R41, R32; V3P o41, o32;              // frames: (link4 | link1), (link3 | link2); tip on link3, knees = origins of link3 and link2
+  SVP s23, sp12;                           // joint axes (dof2 | dof3), (p1 | p2)
   float g1, pd, pdd;                       // closure: dp/dD, passive rate, passive vp-acceleration
-  M3 Rs, R4, R1, R2;
 };
 
 LM_DEV void limb_kinematics(const float* tl, const float q[3], const float qd[3], LimbKin& K) {
-  float s1_, c1_, s2_, c2_, s3_, c3_;
-  lm_sincos(q[0], &s1_, &c1_); lm_sincos(q[1], &s2_, &c2_); lm_sincos(q[2], &s3_, &c3_);
+  float s1_, c1_; f2 s23_, c23_;
+  lm_sincos(q[0], &s1_, &c1_); lm_sincos2(mk2(q[1], q[2]), &s23_, &c23_);
+  const float s2_ = s23_.x, c2_ = c23_.x, s3_ = s23_.y, c3_ = c23_.y;
   float cD = c2_ * c3_ + s2_ * s3_, sD = s2_ * c3_ - c2_ * s3_;      // D = q2 - q3
   float inv = 1.0f / (3.0f - cD);
   float cp = (3.0f * cD - 1.0f) * inv, sp = 2.0f * SQRT2F * sD * inv;
@@ -165,15 +219,17 @@ LM_DEV void limb_kinematics(const float* tl, const float q[3], const float qd[3]
   float g2 = -2.0f * SQRT2F * sD * inv * inv;
   float dd = qd[1] - qd[2];
   K.pd = K.g1 * dd; K.pdd = g2 * dd * dd;
-  M3 I3; I3.c0 = v3(1, 0, 0); I3.c1 = v3(0, 1, 0); I3.c2 = v3(0, 0, 1);
-  V3 z1, z2, zp1, z3, zp2;
-  joint_frame(I3, v3(0, 0, 0), tl + 0, c1_, s1_, K.Rs, K.os, z1);
-  joint_frame(K.Rs, K.os, tl + 13, c2_, s2_, K.R4, K.o4, z2);
-  joint_frame(K.R4, K.o4, tl + 26, cp, sp, K.R3, K.o3, zp1);          // p1 = +g(D)
-  joint_frame(K.Rs, K.os, tl + 39, c3_, s3_, K.R1, K.o1, z3);
-  joint_frame(K.R1, K.o1, tl + 52, cp, -sp, K.R2, K.o2, zp2);         // p2 = -g(D)
-  K.s1 = axis_sv(z1, K.os); K.s2 = axis_sv(z2, K.o4); K.sp1 = axis_sv(zp1, K.o3);
-  K.s3 = axis_sv(z3, K.o1); K.sp2 = axis_sv(zp2, K.o2);
+  const f2* tp = reinterpret_cast<const f2*>(tl);
+  V3 z1; V3P z23, zp12;
+  joint_frame_root(tl + T_J0, c1_, s1_, K.Rs, K.os, z1);
+  joint_frame<f2>(bc(K.Rs), bc(K.os), tp + T_P1 / 2, c23_, s23_, K.R41, K.o41, z23);          // dof2 | dof3
+  joint_frame<f2>(K.R41, K.o41, tp + T_P2 / 2, sp2(cp), mk2(sp, -sp), K.R32, K.o32, zp12);    // p1 = +g(D) | p2 = -g(D)
+  K.s1 = axis_sv(z1, K.os); K.s23 = axis_sv(z23, K.o41); K.sp12 = axis_sv(zp12, K.o32);
+}
+// the fingertip frame (on link3) and the two knee origins of a limb, hub coordinates
+LM_DEV void limb_points(const float* tl, const LimbKin& K, V3& tip, V3& knee2, V3& knee3) {
+  knee3 = lo(K.o32); knee2 = hi(K.o32);
+  tip = knee3 + mul(lo(K.R32), v3(tl[T_TIP], tl[T_TIP + 1], tl[T_TIP + 2]));
 }
 
 struct LimbDyn {
@@ -189,43 +245,44 @@ LM_DEV V3 sel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? 
 LM_DEV SV sel(bool c, SV a, SV b) { return sv(sel(c, a.w, b.w), sel(c, a.v, b.v)); }
 
 LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], SV v0, SV avp0, LimbDyn& D) {
-  SI Is = place_inertia(tl + 65, K.Rs, K.os), I4 = place_inertia(tl + 75, K.R4, K.o4), I3 = place_inertia(tl + 85, K.R3, K.o3);
-  SI I1 = place_inertia(tl + 95, K.R1, K.o1), I2 = place_inertia(tl + 105, K.R2, K.o2);
-  SV j1 = qd[0] * K.s1, j2 = qd[1] * K.s2, jp1 = K.pd * K.sp1, j3 = qd[2] * K.s3, jp2 = (-K.pd) * K.sp2;
-  SV vs = v0 + j1, v4 = vs + j2, v3_ = v4 + jp1, v1 = vs + j3, v2 = v1 + jp2;
-  SV as = avp0 + mcross(v0, j1);
-  SV a4 = as + mcross(vs, j2);
-  SV a3 = fma6(K.pdd, K.sp1, a4 + mcross(v4, jp1));
-  SV a1 = as + mcross(vs, j3);
-  SV a2 = fma6(-K.pdd, K.sp2, a1 + mcross(v1, jp2));
-  SV ps = Is * as + fcross(vs, Is * vs);
-  SV p4 = I4 * a4 + fcross(v4, I4 * v4);
-  SV p3 = I3 * a3 + fcross(v3_, I3 * v3_);
-  SV p1 = I1 * a1 + fcross(v1, I1 * v1);
-  SV p2 = I2 * a2 + fcross(v2, I2 * v2);
-  SV fc4 = p4 + p3, fc1 = p1 + p2;
-  D.fcs = ps + fc4 + fc1;
-  float h1 = sdot(K.s1, D.fcs), h2 = sdot(K.s2, fc4), hp1 = sdot(K.sp1, p3), h3 = sdot(K.s3, fc1), hp2 = sdot(K.sp2, p2);
-  float g1 = K.g1;
-  D.hq[0] = h1; D.hq[1] = h2 + g1 * (hp1 - hp2); D.hq[2] = h3 - g1 * (hp1 - hp2);
-  SI I4c = I4 + I3, I1c = I1 + I2;
-  D.Isc = Is + I4c + I1c;
-  SV F1 = D.Isc * K.s1, F2 = I4c * K.s2, Fp1 = I3 * K.sp1, F3 = I1c * K.s3, Fp2 = I2 * K.sp2;
-  SV dF = Fp1 - Fp2;
-  D.Fq0 = F1; D.Fq1 = fma6(g1, dF, F2); D.Fq2 = fma6(-g1, dF, F3);
-  float H11 = sdot(K.s1, F1), H12 = sdot(K.s1, F2), H1p1 = sdot(K.s1, Fp1), H13 = sdot(K.s1, F3), H1p2 = sdot(K.s1, Fp2);
-  float H22 = sdot(K.s2, F2), H2p1 = sdot(K.s2, Fp1), Hp1p1 = sdot(K.sp1, Fp1);
-  float H33 = sdot(K.s3, F3), H3p2 = sdot(K.s3, Fp2), Hp2p2 = sdot(K.sp2, Fp2);
-  float gg = g1 * g1 * (Hp1p1 + Hp2p2);
-  D.H[0] = H11; D.H[1] = H12 + g1 * (H1p1 - H1p2); D.H[2] = H13 - g1 * (H1p1 - H1p2);
-  D.H[3] = H22 + 2.0f * g1 * H2p1 + gg; D.H[4] = -g1 * (H2p1 + H3p2) - gg; D.H[5] = H33 + 2.0f * g1 * H3p2 + gg;
+  const f2* tp = reinterpret_cast<const f2*>(tl);
+  const SI Is = place_inertia<float>(tl + T_I0, K.Rs, K.os);
+  const SIP I41 = place_inertia<f2>(tp + T_Q1 / 2, K.R41, K.o41), I32 = place_inertia<f2>(tp + T_Q2 / 2, K.R32, K.o32);
+  // velocities / velocity-product accelerations down the two chains
+  const SV j1 = qd[0] * K.s1; const SVP j23 = mk2(qd[1], qd[2]) * K.s23, jp = mk2(K.pd, -K.pd) * K.sp12;
+  const SV vs = v0 + j1; const SVP v41 = bc(vs) + j23, v32 = v41 + jp;
+  const SV as = avp0 + mcross(v0, j1);
+  const SVP a41 = bc(as) + mcross(bc(vs), j23);
+  const SVP a32 = fma6(mk2(K.pdd, -K.pdd), K.sp12, a41 + mcross(v41, jp));
+  // bias wrenches
+  const SV ps = Is * as + fcross(vs, Is * vs);
+  const SVP p41 = I41 * a41 + fcross(v41, I41 * v41), p32 = I32 * a32 + fcross(v32, I32 * v32);
+  const SVP fc = p41 + p32;                                             // (fc4 | fc1)
+  D.fcs = ps + lo(fc) + hi(fc);
+  const float h1 = sdot(K.s1, D.fcs); const f2 h23 = sdot(K.s23, fc), hp = sdot(K.sp12, p32);      // (h2 | h3), (hp1 | hp2)
+  const float g1 = K.g1, dh = hp.x - hp.y;
+  D.hq[0] = h1; D.hq[1] = h23.x + g1 * dh; D.hq[2] = h23.y - g1 * dh;
+  // composite inertias and the columns of the coupling / joint-space inertia
+  const SIP Ic = I41 + I32;                                             // (I4c | I1c)
+  D.Isc = Is + lo(Ic) + hi(Ic);
+  const SV F1 = D.Isc * K.s1; const SVP F23 = Ic * K.s23, Fp = I32 * K.sp12;      // (F2 | F3), (Fp1 | Fp2)
+  const SV dF = lo(Fp) - hi(Fp);
+  D.Fq0 = F1; D.Fq1 = fma6(g1, dF, lo(F23)); D.Fq2 = fma6(-g1, dF, hi(F23));
+  const SVP s1p = bc(K.s1);
+  const float H11 = sdot(K.s1, F1);
+  const f2 H1d = sdot(s1p, F23), H1p = sdot(s1p, Fp);                   // (H12 | H13), (H1p1 | H1p2)
+  const f2 Hdd = sdot(K.s23, F23), Hdp = sdot(K.s23, Fp), Hpp = sdot(K.sp12, Fp);      // (H22 | H33), (H2p1 | H3p2), (Hp1p1 | Hp2p2)
+  const float gg = g1 * g1 * (Hpp.x + Hpp.y), d1p = H1p.x - H1p.y;
+  D.H[0] = H11; D.H[1] = H1d.x + g1 * d1p; D.H[2] = H1d.y - g1 * d1p;
+  D.H[3] = Hdd.x + 2.0f * g1 * Hdp.x + gg; D.H[4] = -g1 * (Hdp.x + Hdp.y) - gg; D.H[5] = Hdd.y + 2.0f * g1 * Hdp.y + gg;
   // foot collider = the hemispherical end of the long distal link (robot_model.py FOOT_*): link3 (chain dof2 -> p1 = +g(D)) on a left-hand
   // module, link2 (chain dof3 -> p2 = -g(D)) on a right-hand one
-  const bool on2 = tl[121] != 0.f;
-  const V3 off = v3(tl[118], tl[119], tl[120]);
-  D.j31 = sel(on2, (-g1) * K.sp2, fma6(g1, K.sp1, K.s2));
-  D.j32 = sel(on2, fma6(g1, K.sp2, K.s3), (-g1) * K.sp1);
-  D.x = sel(on2, K.o2 + mul(K.R2, off), K.o3 + mul(K.R3, off));
+  const bool on2 = tl[T_FLAG] != 0.f;
+  const V3 off = v3(tl[T_FOOT], tl[T_FOOT + 1], tl[T_FOOT + 2]);
+  const SV s2 = lo(K.s23), s3 = hi(K.s23), sp1 = lo(K.sp12), sp2_ = hi(K.sp12);
+  D.j31 = sel(on2, (-g1) * sp2_, fma6(g1, sp1, s2));
+  D.j32 = sel(on2, fma6(g1, sp2_, s3), (-g1) * sp1);
+  D.x = sel(on2, hi(K.o32), lo(K.o32)) + mul(M3{sel(on2, hi(K.R32.c0), lo(K.R32.c0)), sel(on2, hi(K.R32.c1), lo(K.R32.c1)), sel(on2, hi(K.R32.c2), lo(K.R32.c2))}, off);
 }
 
 // Projected Gauss-Seidel over the 4 tip contacts of one env (rows n, t1, t2 per contact, limb order).
@@ -236,20 +293,70 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // with 9 FMAs.  Identical arithmetic (up to rounding) to row-wise PGS on the dense 12x12 system of the oracle.
 struct PgsData { float Wf[6]; float rW[3]; float X[4][9]; };      // X[K]: this contact's 3x3 block towards contact K (K == own limb: the own block)
 
-template <int K>
-LM_DEV void pgs_cross_blocks(int limb, const SV T[3], const SV B[3], const float Wf[6], float X[9]) {
-  SV Bk[3];
+// ---- "four 6-vectors at once" layout of the pass linear algebra.  Component i of the vectors (v0, v1, v2, v3) is an R4: p = (v0[i] | v1[i]),
+// q = (v2[i] | v3[i]), so that an operation applied to all four is two packed-fp32 instructions and any single entry is a free half-register
+// read.  The pass uses it for (-bA, T0, T1, T2) - the hub bias and the three contact rows of this lane - and for what the hub solve makes of
+// them, (a0, B0, B1, B2).
+struct R4 { f2 p, q; };
+// component-pair layout of ONE 6-vector (w.x,w.y | w.z,v.x | v.y,v.z): what a float4 stash reload delivers in aligned register pairs
+struct S6 { f2 a, b, c; };
+LM_DEV S6 operator*(float s, S6 x) { const f2 t = sp2(s); S6 r; r.a = t * x.a; r.b = t * x.b; r.c = t * x.c; return r; }
+LM_DEV S6 fma6(float s, S6 x, S6 y) { const f2 t = sp2(s); S6 r; r.a = fma_(t, x.a, y.a); r.b = fma_(t, x.b, y.b); r.c = fma_(t, x.c, y.c); return r; }
+template <int I> LM_DEV float comp(const S6& x) { return I == 0 ? x.a.x : I == 1 ? x.a.y : I == 2 ? x.b.x : I == 3 ? x.b.y : I == 4 ? x.c.x : x.c.y; }
+template <int J> LM_DEV f2 pairc(const S6& x) { return J == 0 ? x.a : J == 1 ? x.b : x.c; }
+
+// Cholesky factor of a symmetric positive definite 6x6 matrix given by its upper triangle: L (strictly lower) and 1 / diagonal
+struct Chol6 { float L[6][6]; float d[6]; };
+LM_DEV void chol6(const float A[6][6], Chol6& C) {
 #pragma unroll
-  for (int s = 0; s < 3; s++) {
-    Bk[s].w = v3(quad_bcast<K>(B[s].w.x), quad_bcast<K>(B[s].w.y), quad_bcast<K>(B[s].w.z));
-    Bk[s].v = v3(quad_bcast<K>(B[s].v.x), quad_bcast<K>(B[s].v.y), quad_bcast<K>(B[s].v.z));
+  for (int j = 0; j < 6; j++) {
+    float s = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s = fmaf(-C.L[j][k], C.L[j][k], s);
+    const float inv = __builtin_amdgcn_rsqf(s);      // v_rsq_f32 (1 ulp); the pivots are O(1e-3 .. 1): no denormal scaling needed
+    C.d[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float t = A[j][i];
+#pragma unroll
+      for (int k = 0; k < j; k++) t = fmaf(-C.L[i][k], C.L[j][k], t);
+      C.L[i][j] = t * inv;
+    }
+  }
+}
+// A x = b for four right-hand sides at once, in place (forward then backward substitution: 84 packed instructions)
+LM_DEV void chol6_solve4(const Chol6& C, R4 x[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    f2 p = x[i].p, q = x[i].q;
+#pragma unroll
+    for (int k = 0; k < i; k++) { const f2 l = sp2(-C.L[i][k]); p = fma_(l, x[k].p, p); q = fma_(l, x[k].q, q); }
+    const f2 d = sp2(C.d[i]); x[i].p = p * d; x[i].q = q * d;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    f2 p = x[i].p, q = x[i].q;
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) { const f2 l = sp2(-C.L[k][i]); p = fma_(l, x[k].p, p); q = fma_(l, x[k].q, q); }
+    const f2 d = sp2(C.d[i]); x[i].p = p * d; x[i].q = q * d;
+  }
+}
+
+// 3x3 block of this lane's contact rows T_i against the B vectors of contact K:  X[3 r + s] = T_i,r . B_K,s  (K == own limb: the own block)
+template <int K>
+LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float Wf[6], float Xo[9]) {
+  f2 a0 = sp2(0.f), a1 = sp2(0.f), a2 = sp2(0.f); float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const float k0 = quad_bcast<K>(X[i].p.y); const f2 k12 = mk2(quad_bcast<K>(X[i].q.x), quad_bcast<K>(X[i].q.y));
+    const float t0 = T[i].p.y, t1 = T[i].q.x, t2 = T[i].q.y;
+    b0 = fmaf(t0, k0, b0); b1 = fmaf(t1, k0, b1); b2 = fmaf(t2, k0, b2);
+    a0 = fma_(sp2(t0), k12, a0); a1 = fma_(sp2(t1), k12, a1); a2 = fma_(sp2(t2), k12, a2);
   }
   const bool own = (limb == K);
-  const float Wown[9] = {Wf[0], Wf[1], Wf[2], Wf[1], Wf[3], Wf[4], Wf[2], Wf[4], Wf[5]};
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int s = 0; s < 3; s++) X[3 * r + s] = own ? Wown[3 * r + s] : sdot(T[r], Bk[s]);
+  Xo[0] = own ? Wf[0] : b0;   Xo[1] = own ? Wf[1] : a0.x; Xo[2] = own ? Wf[2] : a0.y;
+  Xo[3] = own ? Wf[1] : b1;   Xo[4] = own ? Wf[3] : a1.x; Xo[5] = own ? Wf[4] : a1.y;
+  Xo[6] = own ? Wf[2] : b2;   Xo[7] = own ? Wf[4] : a2.x; Xo[8] = own ? Wf[5] : a2.y;
 }
 
 // One Gauss-Seidel turn: contact K relaxes its rows n, t1, t2 in sequence (each row sees the rows before it through the two
@@ -275,15 +382,24 @@ LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float lam[3], float c
   c[2] = fmaf(X[6], b0, fmaf(X[7], b1, fmaf(X[8], b2, c[2])));
 }
 
+// T[i].p.y, T[i].q = this lane's three contact rows (hub / plate wrench per unit impulse); X[i].p.y, X[i].q = B = Phi T
 LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3], const float Wl[6],
-                      const SV T[3], const SV B[3], float lam[3], SV& w) {
+                      const R4 T[6], const R4 X[6], float lam[3], float w[6]) {
   PgsData G;
   // full own block = limb-local part + hub/plate part T_r^T Phi T_s
-  G.Wf[0] = Wl[0] + sdot(T[0], B[0]); G.Wf[1] = Wl[1] + sdot(T[0], B[1]); G.Wf[2] = Wl[2] + sdot(T[0], B[2]);
-  G.Wf[3] = Wl[3] + sdot(T[1], B[1]); G.Wf[4] = Wl[4] + sdot(T[1], B[2]); G.Wf[5] = Wl[5] + sdot(T[2], B[2]);
+  {
+    f2 a0 = sp2(0.f), a1 = sp2(0.f), a2 = sp2(0.f); float b0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      b0 = fmaf(T[i].p.y, X[i].p.y, b0);
+      a0 = fma_(sp2(T[i].p.y), X[i].q, a0); a1 = fma_(sp2(T[i].q.x), X[i].q, a1); a2 = fma_(sp2(T[i].q.y), X[i].q, a2);
+    }
+    G.Wf[0] = Wl[0] + b0; G.Wf[1] = Wl[1] + a0.x; G.Wf[2] = Wl[2] + a0.y;
+    G.Wf[3] = Wl[3] + a1.x; G.Wf[4] = Wl[4] + a1.y; G.Wf[5] = Wl[5] + a2.y;
+  }
   G.rW[0] = 1.0f / G.Wf[0]; G.rW[1] = 1.0f / G.Wf[3]; G.rW[2] = 1.0f / G.Wf[5];
-  pgs_cross_blocks<0>(limb, T, B, G.Wf, G.X[0]); pgs_cross_blocks<1>(limb, T, B, G.Wf, G.X[1]);
-  pgs_cross_blocks<2>(limb, T, B, G.Wf, G.X[2]); pgs_cross_blocks<3>(limb, T, B, G.Wf, G.X[3]);
+  pgs_cross_blocks<0>(limb, T, X, G.Wf, G.X[0]); pgs_cross_blocks<1>(limb, T, X, G.Wf, G.X[1]);
+  pgs_cross_blocks<2>(limb, T, X, G.Wf, G.X[2]); pgs_cross_blocks<3>(limb, T, X, G.Wf, G.X[3]);
   lam[0] = lam[1] = lam[2] = 0.f;
   float c[3] = {vf[0] + bn, vf[1], vf[2]};
   // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
@@ -301,7 +417,9 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
     }
   }
   // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
-  w = quad_sum(fma6(lam[0], B[0], fma6(lam[1], B[1], lam[2] * B[2])));
+  const f2 l12 = mk2(lam[1], lam[2]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) { const f2 t = l12 * X[i].q; w[i] = quad_sum(fmaf(lam[0], X[i].p.y, t.x + t.y)); }
 }
 
 // free rigid body carried as (position, quaternion, body-coordinate spatial velocity about its origin)
@@ -402,8 +520,9 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
 #pragma unroll
         for (int j = 0; j < 6; j++) Ph[i][j] = P->plate_phi[6 * i + j];
       SV up_free = F.u - dt * mul66(Ph, hp);
-      stash_sv3(St, 12, Tp0, Tp1, Tp2);
-      St.put(17, up_free.w.x, up_free.w.y, up_free.w.z, up_free.v.x); St.put(18, up_free.v.y, up_free.v.z, 0.f, 0.f);
+      // pass-invariant contact rows in the four-vector layout: slots 10-12 (up_free[i] | Tp0[i]), slots 13-15 (Tp1[i] | Tp2[i])
+      St.put(10, up_free.w.x, Tp0.w.x, up_free.w.y, Tp0.w.y); St.put(11, up_free.w.z, Tp0.w.z, up_free.v.x, Tp0.v.x); St.put(12, up_free.v.y, Tp0.v.y, up_free.v.z, Tp0.v.z);
+      St.put(13, Tp1.w.x, Tp2.w.x, Tp1.w.y, Tp2.w.y); St.put(14, Tp1.w.z, Tp2.w.z, Tp1.v.x, Tp2.v.x); St.put(15, Tp1.v.y, Tp2.v.y, Tp1.v.z, Tp2.v.z);
     }
     bn = (phi >= 0.f) ? phi / dt : fmaxf(P->baumgarte * phi / dt, -P->max_depen_vel);
     // tip linear velocity per unit generalized rate, contact coordinates
@@ -412,12 +531,16 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     V3 e2 = D.j32.v + cross(D.j32.w, D.x);
     stash_sv3(St, 0, D.Fq0, D.Fq1, D.Fq2);
     St.put(5, D.H[0], D.H[1], D.H[2], D.H[3]); St.put(6, D.H[4], D.H[5], D.hq[0], D.hq[1]);
+    // Jq = contact-coordinate tip velocity per unit joint rate: row 0 plain, rows 1 and 2 interleaved (Jq[1][c] | Jq[2][c])
     St.put(7, D.hq[2], dot(C0, e0), dot(C0, e1), dot(C0, e2));
-    St.put(8, dot(C1, e0), dot(C1, e1), dot(C1, e2), dot(C2, e0)); St.put(9, dot(C2, e1), dot(C2, e2), 0.f, 0.f);
+    St.put(8, dot(C1, e0), dot(C2, e0), dot(C1, e1), dot(C2, e1)); St.put(9, dot(C1, e2), dot(C2, e2), 0.f, 0.f);
     if (MODE == 0) {
-      St.put(10, D.fcs.w.x, D.fcs.w.y, D.fcs.w.z, D.fcs.v.x); St.put(11, D.fcs.v.y, D.fcs.v.z, D.Isc.m, D.Isc.h.x);
-      St.put(12, D.Isc.h.y, D.Isc.h.z, D.Isc.xx, D.Isc.yy); St.put(13, D.Isc.zz, D.Isc.xy, D.Isc.xz, D.Isc.yz);
-      St.put(14, D.x.x, D.x.y, D.x.z, C0.x); St.put(15, C0.y, C0.z, C1.x, C1.y); St.put(16, C1.z, C2.x, C2.y, C2.z);
+      // hub rows Jb_r = [x x C_r ; C_r] of the three contact axes and the limb's bias wrench, in the four-vector layout:
+      // slots 10-12 (fcs[i] | Jb0[i]), slots 13-15 (Jb1[i] | Jb2[i]); slots 16-18 the limb's composite inertia
+      const V3 n0 = cross(D.x, C0), n1 = cross(D.x, C1), n2 = cross(D.x, C2);
+      St.put(10, D.fcs.w.x, n0.x, D.fcs.w.y, n0.y); St.put(11, D.fcs.w.z, n0.z, D.fcs.v.x, C0.x); St.put(12, D.fcs.v.y, C0.y, D.fcs.v.z, C0.z);
+      St.put(13, n1.x, n2.x, n1.y, n2.y); St.put(14, n1.z, n2.z, C1.x, C2.x); St.put(15, C1.y, C2.y, C1.z, C2.z);
+      St.put(16, D.Isc.m, D.Isc.h.x, D.Isc.h.y, D.Isc.h.z); St.put(17, D.Isc.xx, D.Isc.yy, D.Isc.zz, D.Isc.xy); St.put(18, D.Isc.xz, D.Isc.yz, 0.f, 0.f);
     }
   }
 
@@ -425,60 +548,91 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   float qdn[3]; SV un;
   for (int pass = 0; pass < 2; pass++) {
     asm volatile("" ::: "memory");          // keep the stash reloads inside the pass (no hoisting across the PGS loop)
-    SV Fq0, Fq1, Fq2; unstash_sv3(St, 0, Fq0, Fq1, Fq2);
-    float4 h5 = St.get(5), h6 = St.get(6), h7 = St.get(7), h8 = St.get(8), h9 = St.get(9);
+    S6 Fq0, Fq1, Fq2;
+    {
+      const float4 t0 = St.get(0), t1 = St.get(1), t2 = St.get(2), t3 = St.get(3), t4 = St.get(4);
+      Fq0.a = mk2(t0.x, t0.y); Fq0.b = mk2(t0.z, t0.w); Fq0.c = mk2(t1.x, t1.y);
+      Fq1.a = mk2(t1.z, t1.w); Fq1.b = mk2(t2.x, t2.y); Fq1.c = mk2(t2.z, t2.w);
+      Fq2.a = mk2(t3.x, t3.y); Fq2.b = mk2(t3.z, t3.w); Fq2.c = mk2(t4.x, t4.y);
+    }
+    const float4 h5 = St.get(5), h6 = St.get(6), h7 = St.get(7), h8 = St.get(8), h9 = St.get(9);
     float Ha[6] = {h5.x, h5.y, h5.z, h5.w, h6.x, h6.y}, r[3];
     const float hq[3] = {h6.z, h6.w, h7.x};
-    const float Jq[3][3] = {{h7.y, h7.z, h7.w}, {h8.x, h8.y, h8.z}, {h8.w, h9.x, h9.y}};
+    const float Jq[3][3] = {{h7.y, h7.z, h7.w}, {h8.x, h8.z, h9.x}, {h8.y, h8.w, h9.y}};
+    const f2 j12[3] = {mk2(h8.x, h8.y), mk2(h8.z, h8.w), mk2(h9.x, h9.y)};      // (Jq[1][c] | Jq[2][c])
     const int di[3] = {0, 3, 5};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const float cj = cjv[a];
-      if (!sat[a]) { Ha[di[a]] += dt * (kd + cj); r[a] = kd * (tgt[a] - qd[a]) - cj * qd[a] - hq[a]; }
-      else { Ha[di[a]] += dt * cj; r[a] = tsat[a] - cj * qd[a] - hq[a]; }      // viscous joint damping is implicit in both cases
+      const float dd = sat[a] ? dt * cj : dt * (kd + cj);                  // viscous joint damping is implicit in both cases
+      const float rr = sat[a] ? tsat[a] : kd * (tgt[a] - qd[a]);
+      Ha[di[a]] += dd; r[a] = rr - cj * qd[a] - hq[a];
     }
     float Hi[6]; inv3sym(Ha, Hi);
     // K = Fq Hinv  (columns)
-    SV K0 = fma6(Hi[0], Fq0, fma6(Hi[1], Fq1, Hi[2] * Fq2));
-    SV K1 = fma6(Hi[1], Fq0, fma6(Hi[3], Fq1, Hi[4] * Fq2));
-    SV K2 = fma6(Hi[2], Fq0, fma6(Hi[4], Fq1, Hi[5] * Fq2));
-    float qdd[3], qdf[3]; SV v0f; float Phi[6][6];
-    SV T[3];
+    const S6 K0 = fma6(Hi[0], Fq0, fma6(Hi[1], Fq1, Hi[2] * Fq2));
+    const S6 K1 = fma6(Hi[1], Fq0, fma6(Hi[3], Fq1, Hi[4] * Fq2));
+    const S6 K2 = fma6(Hi[2], Fq0, fma6(Hi[4], Fq1, Hi[5] * Fq2));
+    float qdd[3], qdf[3], v0f[6], vf[3];
+    R4 T[6], X[6];
+    // pass-invariant rows (slots 10-15): PB[i].p = (fcs[i] | Jb0[i]) or (up_free[i] | Tp0[i]),  PB[i].q = (row 1 | row 2)
+    R4 PB[6];
+    {
+      const float4 g0 = St.get(10), g1 = St.get(11), g2 = St.get(12), g3 = St.get(13), g4 = St.get(14), g5 = St.get(15);
+      PB[0].p = mk2(g0.x, g0.y); PB[1].p = mk2(g0.z, g0.w); PB[2].p = mk2(g1.x, g1.y); PB[3].p = mk2(g1.z, g1.w); PB[4].p = mk2(g2.x, g2.y); PB[5].p = mk2(g2.z, g2.w);
+      PB[0].q = mk2(g3.x, g3.y); PB[1].q = mk2(g3.z, g3.w); PB[2].q = mk2(g4.x, g4.y); PB[3].q = mk2(g4.z, g4.w); PB[4].q = mk2(g5.x, g5.y); PB[5].q = mk2(g5.z, g5.w);
+    }
     if (MODE == 0) {
-      float4 g10 = St.get(10), g11 = St.get(11), g12 = St.get(12), g13 = St.get(13);
-      SV fcs = sv(v3(g10.x, g10.y, g10.z), v3(g10.w, g11.x, g11.y));
-      SI Isc; Isc.m = g11.z; Isc.h = v3(g11.w, g12.x, g12.y); Isc.xx = g12.z; Isc.yy = g12.w; Isc.zz = g13.x; Isc.xy = g13.y; Isc.xz = g13.z; Isc.yz = g13.w;
-      float A[6][6]; si_to_66(Isc, A);
-      float k0[6], k1[6], k2[6], f0[6], f1[6], f2[6];
-      sv_to_arr(K0, k0); sv_to_arr(K1, k1); sv_to_arr(K2, k2); sv_to_arr(Fq0, f0); sv_to_arr(Fq1, f1); sv_to_arr(Fq2, f2);
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++) A[i][j] = quad_sum(A[i][j] - (k0[i] * f0[j] + k1[i] * f1[j] + k2[i] * f2[j]));
-      SV bA = quad_sum(fma6(r[0], K0, fma6(r[1], K1, fma6(r[2], K2, fcs))));
-      inv6spd(A, Phi);
-      SV a0 = mul66(Phi, sv(-bA.w, -bA.v));
-      float t0 = r[0] - sdot(Fq0, a0), t1 = r[1] - sdot(Fq1, a0), t2 = r[2] - sdot(Fq2, a0);
+      const float4 g16 = St.get(16), g17 = St.get(17), g18 = St.get(18);
+      SI Isc; Isc.m = g16.x; Isc.h = v3(g16.y, g16.z, g16.w); Isc.xx = g17.x; Isc.yy = g17.y; Isc.zz = g17.z; Isc.xy = g17.w; Isc.xz = g18.x; Isc.yz = g18.y;
+      // articulated hub inertia  A = sum over the quad of (Isc - K F^T): rows of pairs, upper triangle only
+      float A0[6][6]; si_to_66(Isc, A0);
+      float A[6][6];
+#define LM_AROW(I) { \
+        const f2 k0 = sp2(comp<I>(K0)), k1 = sp2(comp<I>(K1)), k2 = sp2(comp<I>(K2)); \
+        _Pragma("unroll") for (int jp = (I) / 2; jp < 3; jp++) { \
+          const f2 f0 = jp == 0 ? Fq0.a : jp == 1 ? Fq0.b : Fq0.c, f1 = jp == 0 ? Fq1.a : jp == 1 ? Fq1.b : Fq1.c, f2_ = jp == 0 ? Fq2.a : jp == 1 ? Fq2.b : Fq2.c; \
+          const f2 v = fma_(-k2, f2_, fma_(-k1, f1, fma_(-k0, f0, mk2(A0[I][2 * jp], A0[I][2 * jp + 1])))); \
+          if (2 * jp >= (I)) A[I][2 * jp] = quad_sum(v.x); \
+          A[I][2 * jp + 1] = quad_sum(v.y); } }
+      LM_AROW(0) LM_AROW(1) LM_AROW(2) LM_AROW(3) LM_AROW(4) LM_AROW(5)
+#undef LM_AROW
+      Chol6 Ch; chol6(A, Ch);
+      // (bias | row 0) and (row 1 | row 2) with the limb's joints eliminated:  P = PB + coefficient x K,  T_r = Jb_r - K Jq_r^T
+      const f2 cp[3] = {mk2(r[0], -Jq[0][0]), mk2(r[1], -Jq[0][1]), mk2(r[2], -Jq[0][2])};
+#define LM_PROW(I) { \
+        const f2 k0 = sp2(comp<I>(K0)), k1 = sp2(comp<I>(K1)), k2 = sp2(comp<I>(K2)); \
+        T[I].p = fma_(cp[2], k2, fma_(cp[1], k1, fma_(cp[0], k0, PB[I].p))); \
+        T[I].q = fma_(-j12[2], k2, fma_(-j12[1], k1, fma_(-j12[0], k0, PB[I].q))); \
+        X[I].p = mk2(-quad_sum(T[I].p.x), T[I].p.y); X[I].q = T[I].q; }
+      LM_PROW(0) LM_PROW(1) LM_PROW(2) LM_PROW(3) LM_PROW(4) LM_PROW(5)
+#undef LM_PROW
+      chol6_solve4(Ch, X);          // X = (a0 | B0), (B1 | B2): hub acceleration and Phi T without forming Phi
+      float t0 = r[0], t1 = r[1], t2 = r[2];
+#define LM_TROW(I) { const float a = X[I].p.x; t0 = fmaf(-comp<I>(Fq0), a, t0); t1 = fmaf(-comp<I>(Fq1), a, t1); t2 = fmaf(-comp<I>(Fq2), a, t2); }
+      LM_TROW(0) LM_TROW(1) LM_TROW(2) LM_TROW(3) LM_TROW(4) LM_TROW(5)
+#undef LM_TROW
       qdd[0] = Hi[0] * t0 + Hi[1] * t1 + Hi[2] * t2; qdd[1] = Hi[1] * t0 + Hi[3] * t1 + Hi[4] * t2; qdd[2] = Hi[2] * t0 + Hi[4] * t1 + Hi[5] * t2;
-      v0f = fma6(dt, a0, F.u);
-      // T = Jb^T - K Jq^T  (hub wrench produced by a unit contact impulse), Jb_r = [x x C_r ; C_r]
-      float4 g14 = St.get(14), g15 = St.get(15), g16 = St.get(16);
-      V3 x = v3(g14.x, g14.y, g14.z), C0 = v3(g14.w, g15.x, g15.y), C1 = v3(g15.z, g15.w, g16.x), C2 = v3(g16.y, g16.z, g16.w);
-      T[0] = sv(cross(x, C0), C0); T[1] = sv(cross(x, C1), C1); T[2] = sv(cross(x, C2), C2);
+      const float u6[6] = {F.u.w.x, F.u.w.y, F.u.w.z, F.u.v.x, F.u.v.y, F.u.v.z};
+#pragma unroll
+      for (int i = 0; i < 6; i++) v0f[i] = fmaf(dt, X[i].p.x, u6[i]);
     } else {
       qdd[0] = Hi[0] * r[0] + Hi[1] * r[1] + Hi[2] * r[2]; qdd[1] = Hi[1] * r[0] + Hi[3] * r[1] + Hi[4] * r[2]; qdd[2] = Hi[2] * r[0] + Hi[4] * r[1] + Hi[5] * r[2];
-      float4 g17 = St.get(17), g18 = St.get(18);
-      v0f = sv(v3(g17.x, g17.y, g17.z), v3(g17.w, g18.x, g18.y));
-      unstash_sv3(St, 12, T[0], T[1], T[2]);
 #pragma unroll
-      for (int i = 0; i < 6; i++)
+      for (int i = 0; i < 6; i++) { v0f[i] = PB[i].p.x; T[i] = PB[i]; }
+      // B = Phi T with the plate's constant inverse inertia
 #pragma unroll
-        for (int j = 0; j < 6; j++) Phi[i][j] = P->plate_phi[6 * i + j];
+      for (int i = 0; i < 6; i++) {
+        f2 bp = sp2(0.f), bq = sp2(0.f);
+#pragma unroll
+        for (int j = 0; j < 6; j++) { const f2 ph = sp2(P->plate_phi[6 * i + j]); bp = fma_(ph, T[j].p, bp); bq = fma_(ph, T[j].q, bq); }
+        X[i].p = bp; X[i].q = bq;
+      }
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) qdf[a] = fmaf(dt, qdd[a], qd[a]);
     // contact operator
-    SV B[3]; float Wl[6], vf[3];
+    float Wl[6];
     float JH[3][3];   // Jq * Hinv
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
@@ -492,31 +646,33 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     Wl[3] = JH[1][0] * Jq[1][0] + JH[1][1] * Jq[1][1] + JH[1][2] * Jq[1][2];
     Wl[4] = JH[1][0] * Jq[2][0] + JH[1][1] * Jq[2][1] + JH[1][2] * Jq[2][2];
     Wl[5] = JH[2][0] * Jq[2][0] + JH[2][1] * Jq[2][1] + JH[2][2] * Jq[2][2];
+    // free contact-space velocity: hub / plate rows (before the joints were eliminated) on v0f, plus the joint part
+    {
+      float a = 0.f; f2 b = sp2(0.f);
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-      float vq = Jq[rr][0] * qdf[0] + Jq[rr][1] * qdf[1] + Jq[rr][2] * qdf[2];
-      if (MODE == 0) {
-        vf[rr] = sdot(T[rr], v0f) + vq;                                   // hub row Jb_r (before the -K Jq^T part is folded in)
-        T[rr] = T[rr] - fma6(Jq[rr][0], K0, fma6(Jq[rr][1], K1, Jq[rr][2] * K2));
-      } else {
-        vf[rr] = sdot(T[rr], v0f) + vq;
-      }
-      B[rr] = mul66(Phi, T[rr]);
+      for (int i = 0; i < 6; i++) { a = fmaf(PB[i].p.y, v0f[i], a); b = fma_(PB[i].q, sp2(v0f[i]), b); }
+      vf[0] = a + (Jq[0][0] * qdf[0] + Jq[0][1] * qdf[1] + Jq[0][2] * qdf[2]);
+      vf[1] = b.x + (Jq[1][0] * qdf[0] + Jq[1][1] * qdf[1] + Jq[1][2] * qdf[2]);
+      vf[2] = b.y + (Jq[2][0] * qdf[0] + Jq[2][1] * qdf[1] + Jq[2][2] * qdf[2]);
     }
-    float lam[3]; SV w;
-    pgs_solve(P->pgs_iters, limb, P->mu, bn, vf, Wl, T, B, lam, w);
+    float lam[3], w[6];
+    pgs_solve(P->pgs_iters, limb, P->mu, bn, vf, Wl, T, X, lam, w);
     // apply impulses
-    un = v0f + w;
+    un = sv(v3(v0f[0] + w[0], v0f[1] + w[1], v0f[2] + w[2]), v3(v0f[3] + w[3], v0f[4] + w[4], v0f[5] + w[5]));
 #pragma unroll
     for (int a = 0; a < 3; a++) qdn[a] = qdf[a] + JH[0][a] * lam[0] + JH[1][a] * lam[1] + JH[2][a] * lam[2];
-    if (MODE == 0) { qdn[0] -= sdot(K0, w); qdn[1] -= sdot(K1, w); qdn[2] -= sdot(K2, w); }
+    if (MODE == 0) {
+#define LM_WROW(I) { qdn[0] = fmaf(-comp<I>(K0), w[I], qdn[0]); qdn[1] = fmaf(-comp<I>(K1), w[I], qdn[1]); qdn[2] = fmaf(-comp<I>(K2), w[I], qdn[2]); }
+      LM_WROW(0) LM_WROW(1) LM_WROW(2) LM_WROW(3) LM_WROW(4) LM_WROW(5)
+#undef LM_WROW
+    }
     if (pass == 0) {
       int any = 0;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        float tau = kd * (tgt[a] - qdn[a]);
-        if (tau > tmax[a]) { sat[a] = true; tsat[a] = tmax[a]; any = 1; }
-        else if (tau < -tmax[a]) { sat[a] = true; tsat[a] = -tmax[a]; any = 1; }
+        const float tau = kd * (tgt[a] - qdn[a]);
+        const bool hi_ = tau > tmax[a], lo_ = tau < -tmax[a];
+        sat[a] = hi_ || lo_; tsat[a] = hi_ ? tmax[a] : -tmax[a]; any |= (hi_ || lo_) ? 1 : 0;
       }
       any = quad_sum_i(any);
       if (!__any(any)) break;                  // wave-uniform: nobody saturated
@@ -784,20 +940,20 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
 }
 
 LM_DEV void load_table(const float* __restrict__ table, float* sTab, int lane) {
-  for (int i = lane; i < LM_TABLE_FLOATS; i += 64) sTab[i] = table[i];
+  for (int i = lane; i < LM_ITAB_FLOATS; i += 64) sTab[i] = table[i];
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
 }
 // the same in two halves so that the table's round trip overlaps the state loads of the step kernel
-#define TABLE_REGS ((LM_TABLE_FLOATS + 63) / 64)
+#define TABLE_REGS ((LM_ITAB_FLOATS + 63) / 64)
 struct TableRegs { float v[TABLE_REGS]; };
 LM_DEV void table_fetch(const float* __restrict__ table, int lane, TableRegs& T) {
 #pragma unroll
-  for (int j = 0; j < TABLE_REGS; j++) { int i = lane + 64 * j; T.v[j] = (i < LM_TABLE_FLOATS) ? table[i] : 0.f; }
+  for (int j = 0; j < TABLE_REGS; j++) { int i = lane + 64 * j; T.v[j] = (i < LM_ITAB_FLOATS) ? table[i] : 0.f; }
 }
 LM_DEV void table_commit(const TableRegs& T, float* sTab, int lane) {
 #pragma unroll
-  for (int j = 0; j < TABLE_REGS; j++) { int i = lane + 64 * j; if (i < LM_TABLE_FLOATS) sTab[i] = T.v[j]; }
+  for (int j = 0; j < TABLE_REGS; j++) { int i = lane + 64 * j; if (i < LM_ITAB_FLOATS) sTab[i] = T.v[j]; }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
 }
@@ -981,9 +1137,9 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   {
     LimbKin K; float z3[3] = {0.f, 0.f, 0.f};
     limb_kinematics(tl, q, z3, K);
-    V3 x = K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117]));
+    V3 x, k2, k3; limb_points(tl, K, x, k2, k3);
     M3 Rb = (MODE == 0) ? Rf : Rfix; V3 pb = (MODE == 0) ? F.p : pfix;
-    I.tipw = pb + mul(Rb, x); I.knee2 = pb + mul(Rb, K.o2); I.knee3 = pb + mul(Rb, K.o3);
+    I.tipw = pb + mul(Rb, x); I.knee2 = pb + mul(Rb, k2); I.knee3 = pb + mul(Rb, k3);
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (pd && qda_set) ? (qd[a] - qda[a]) * P->acc_dt_inv : (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a];
@@ -1018,7 +1174,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
 }
 
 __global__ void __launch_bounds__(64) k_step(StepArgs A) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
@@ -1031,7 +1187,7 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
 
 // the same step with domain randomisation (a separate kernel so that the un-randomised k_step above is untouched)
 __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
@@ -1067,7 +1223,7 @@ template <int NOBS> struct PolicySmem<NOBS, LM_POLICY_GNN> { GnnSmem M; };
 
 template <int NOBS, int POLICY>
 __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
@@ -1232,7 +1388,7 @@ LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sT
   if (active) store_phys<MODE>(A.state, N, env, limb, F, q, qd);
 }
 __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* targets, int n) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   __shared__ float4 sStash[STASH_SLOTS * 64];
   load_table(A.table, sTab, threadIdx.x);
   const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
@@ -1241,7 +1397,7 @@ __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* target
 }
 
 __global__ void __launch_bounds__(64) k_fk(StepArgs A, float* tips, float* knees) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   load_table(A.table, sTab, threadIdx.x);
   const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
@@ -1253,15 +1409,16 @@ __global__ void __launch_bounds__(64) k_fk(StepArgs A, float* tips, float* knees
   else { load_phys<1>(A.state, N, env, limb, F, q, qd); Rb = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
          pb = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]); }
   LimbKin K; float z3[3] = {0, 0, 0}; limb_kinematics(tl, q, z3, K);
-  V3 x = pb + mul(Rb, K.o3 + mul(K.R3, v3(tl[115], tl[116], tl[117])));
-  V3 k2 = pb + mul(Rb, K.o2), k3 = pb + mul(Rb, K.o3);
+  V3 xh, k2h, k3h; limb_points(tl, K, xh, k2h, k3h);
+  V3 x = pb + mul(Rb, xh);
+  V3 k2 = pb + mul(Rb, k2h), k3 = pb + mul(Rb, k3h);
   float* t = tips + ((size_t)env * 4 + limb) * 3; t[0] = x.x; t[1] = x.y; t[2] = x.z;
   float* kk = knees + ((size_t)env * 8 + 2 * limb) * 3; kk[0] = k2.x; kk[1] = k2.y; kk[2] = k2.z; kk[3] = k3.x; kk[4] = k3.y; kk[5] = k3.z;
 }
 
 // dense M (18x18) and h (18) of the loco system from the limb-aggregate terms (bring-up / parity tests)
 __global__ void __launch_bounds__(64) k_debug_dyn(StepArgs A, float* Mout, float* hout) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_TABLE_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   load_table(A.table, sTab, threadIdx.x);
   const lm_params* P = A.params;
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
@@ -1409,7 +1566,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); lm_destroy(h); return LM_EHIP; } \
     e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMemset: %s", hipGetErrorString(e_)); lm_destroy(h); return LM_EHIP; } } while (0)
   ALLOC(h->d_params, 2 * sizeof(lm_params));
-  ALLOC(h->d_table, LM_TABLE_FLOATS * sizeof(float));
+  ALLOC(h->d_table, LM_ITAB_FLOATS * sizeof(float));
   ALLOC(h->d_state, LM_STATE_ROWS * N * sizeof(float));
   ALLOC(h->d_cnt, LM_CNT_ROWS * N * sizeof(int64_t));
   ALLOC(h->d_drc, LM_DR_CNT_ROWS * N * sizeof(int64_t));
@@ -1422,8 +1579,9 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_acc, 16 * sizeof(long long));
   ALLOC(h->d_stats, 64);
 #undef ALLOC
+  float itab[LM_ITAB_FLOATS]; permute_table(table, itab);      // public packed layout -> the device's chain-interleaved layout
   if (hipMemcpy(h->d_params, h->h_params, 2 * sizeof(lm_params), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(h->d_table, table, LM_TABLE_FLOATS * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(h->d_table, itab, LM_ITAB_FLOATS * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
     lm_destroy(h); return fail(LM_EHIP, "lm_create: parameter / table upload failed");
   }
   // identity quaternions so that an un-reset state is still valid; reset_buf = 1 (rl_task.py:111)

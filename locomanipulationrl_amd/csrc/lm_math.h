@@ -1,32 +1,56 @@
 // lm_math.h -- device-side vector / quaternion / spatial algebra for the CDNA4 step kernel.
 // All quantities are fp32 in registers; small structs with named members so that nothing is
 // runtime-indexed (runtime-indexed arrays would go to scratch on gfx950).
+//
+// Every type is a template over its scalar T in {float, f2}.  f2 = two floats in an aligned VGPR pair: arithmetic on it compiles to the
+// packed fp32 instructions of gfx90a+ (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 results per lane per issue slot, the rate the
+// 157 TFLOP/s vector peak is quoted at), and a plain float used as an operand of a packed op is broadcast by the instruction's op_sel bits,
+// without a move.  The step kernel uses the pair to run the two structurally identical chains of a limb
+// (shell -> link4 -> link3 and shell -> link1 -> link2) in the same instructions (lm_engine.hip, limb_kinematics / limb_dynamics).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define LM_DEV __device__ __forceinline__
 
-struct V3 { float x, y, z; };
-struct M3 { V3 c0, c1, c2; };          // columns
-struct SV { V3 w, v; };                // spatial motion [omega; v_O]  or force [n_O; f]
-struct SI { float m; V3 h; float xx, yy, zz, xy, xz, yz; };   // spatial inertia about O: mass, h = m*c, I_O
+typedef float f2 __attribute__((ext_vector_type(2)));
+LM_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+LM_DEV f2 sp2(float a) { return mk2(a, a); }
+LM_DEV float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+LM_DEV f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-LM_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-LM_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-LM_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-LM_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
-LM_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
-LM_DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
-LM_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-LM_DEV V3 fma3(float s, V3 a, V3 b) { return v3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }   // s*a + b
+template <class T> struct V3T { T x, y, z; };
+template <class T> struct M3T { V3T<T> c0, c1, c2; };          // columns
+template <class T> struct SVT { V3T<T> w, v; };                // spatial motion [omega; v_O]  or force [n_O; f]
+template <class T> struct SIT { T m; V3T<T> h; T xx, yy, zz, xy, xz, yz; };   // spatial inertia about O: mass, h = m*c, I_O
+typedef V3T<float> V3; typedef M3T<float> M3; typedef SVT<float> SV; typedef SIT<float> SI;
+typedef V3T<f2> V3P; typedef M3T<f2> M3P; typedef SVT<f2> SVP; typedef SIT<f2> SIP;
 
-LM_DEV V3 mul(const M3& A, V3 v) { return fma3(v.x, A.c0, fma3(v.y, A.c1, v.z * A.c2)); }
-LM_DEV V3 mulT(const M3& A, V3 v) { return v3(dot(A.c0, v), dot(A.c1, v), dot(A.c2, v)); }
-LM_DEV M3 mul(const M3& A, const M3& B) { M3 r; r.c0 = mul(A, B.c0); r.c1 = mul(A, B.c1); r.c2 = mul(A, B.c2); return r; }
-LM_DEV M3 mulTA(const M3& A, const M3& B) { M3 r; r.c0 = mulT(A, B.c0); r.c1 = mulT(A, B.c1); r.c2 = mulT(A, B.c2); return r; }  // A^T B
+template <class T> LM_DEV V3T<T> v3t(T x, T y, T z) { V3T<T> r; r.x = x; r.y = y; r.z = z; return r; }
+LM_DEV V3 v3(float x, float y, float z) { return v3t<float>(x, y, z); }
+LM_DEV V3P v3(f2 x, f2 y, f2 z) { return v3t<f2>(x, y, z); }
+template <class T> LM_DEV V3T<T> operator+(V3T<T> a, V3T<T> b) { return v3t<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> LM_DEV V3T<T> operator-(V3T<T> a, V3T<T> b) { return v3t<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> LM_DEV V3T<T> operator-(V3T<T> a) { return v3t<T>(-a.x, -a.y, -a.z); }
+template <class T> LM_DEV V3T<T> operator*(T s, V3T<T> a) { return v3t<T>(s * a.x, s * a.y, s * a.z); }
+template <class T> LM_DEV T dot(V3T<T> a, V3T<T> b) { return fma_(a.x, b.x, fma_(a.y, b.y, a.z * b.z)); }
+template <class T> LM_DEV V3T<T> cross(V3T<T> a, V3T<T> b) { return v3t<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <class T> LM_DEV V3T<T> fma3(T s, V3T<T> a, V3T<T> b) { return v3t<T>(fma_(s, a.x, b.x), fma_(s, a.y, b.y), fma_(s, a.z, b.z)); }   // s*a + b
+
+template <class T> LM_DEV V3T<T> mul(const M3T<T>& A, V3T<T> v) { return fma3(v.x, A.c0, fma3(v.y, A.c1, v.z * A.c2)); }
+template <class T> LM_DEV V3T<T> mulT(const M3T<T>& A, V3T<T> v) { return v3t<T>(dot(A.c0, v), dot(A.c1, v), dot(A.c2, v)); }
+template <class T> LM_DEV M3T<T> mul(const M3T<T>& A, const M3T<T>& B) { M3T<T> r; r.c0 = mul(A, B.c0); r.c1 = mul(A, B.c1); r.c2 = mul(A, B.c2); return r; }
+template <class T> LM_DEV M3T<T> mulTA(const M3T<T>& A, const M3T<T>& B) { M3T<T> r; r.c0 = mulT(A, B.c0); r.c1 = mulT(A, B.c1); r.c2 = mulT(A, B.c2); return r; }  // A^T B
 LM_DEV V3 row0(const M3& A) { return v3(A.c0.x, A.c1.x, A.c2.x); }
 LM_DEV V3 row1(const M3& A) { return v3(A.c0.y, A.c1.y, A.c2.y); }
 LM_DEV V3 row2(const M3& A) { return v3(A.c0.z, A.c1.z, A.c2.z); }
+
+// pair <-> scalar: bc = the same value in both halves (free as an operand of a packed instruction), lo / hi = the halves (free)
+LM_DEV V3P bc(V3 a) { return v3(sp2(a.x), sp2(a.y), sp2(a.z)); }
+LM_DEV M3P bc(const M3& A) { M3P r; r.c0 = bc(A.c0); r.c1 = bc(A.c1); r.c2 = bc(A.c2); return r; }
+LM_DEV V3 lo(V3P a) { return v3(a.x.x, a.y.x, a.z.x); }
+LM_DEV V3 hi(V3P a) { return v3(a.x.y, a.y.y, a.z.y); }
+LM_DEV M3 lo(const M3P& A) { M3 r; r.c0 = lo(A.c0); r.c1 = lo(A.c1); r.c2 = lo(A.c2); return r; }
+LM_DEV M3 hi(const M3P& A) { M3 r; r.c0 = hi(A.c0); r.c1 = hi(A.c1); r.c2 = hi(A.c2); return r; }
 
 // quaternion (w,x,y,z) -> rotation matrix (columns)
 LM_DEV M3 quat_to_mat(float w, float x, float y, float z) {
@@ -48,36 +72,41 @@ LM_DEV Q4 qmul(Q4 a, Q4 b) {
 LM_DEV Q4 qconj(Q4 a) { Q4 r; r.w = a.w; r.x = -a.x; r.y = -a.y; r.z = -a.z; return r; }
 
 // ---- spatial algebra (everything expressed in one frame, about one origin O)
-LM_DEV SV sv(V3 w, V3 v) { SV r; r.w = w; r.v = v; return r; }
-LM_DEV SV operator+(SV a, SV b) { return sv(a.w + b.w, a.v + b.v); }
-LM_DEV SV operator-(SV a, SV b) { return sv(a.w - b.w, a.v - b.v); }
-LM_DEV SV operator*(float s, SV a) { return sv(s * a.w, s * a.v); }
-LM_DEV SV fma6(float s, SV a, SV b) { return sv(fma3(s, a.w, b.w), fma3(s, a.v, b.v)); }
-LM_DEV float sdot(SV a, SV b) { return dot(a.w, b.w) + dot(a.v, b.v); }
-LM_DEV SV mcross(SV a, SV b) { return sv(cross(a.w, b.w), cross(a.w, b.v) + cross(a.v, b.w)); }        // motion x motion
-LM_DEV SV fcross(SV a, SV f) { return sv(cross(a.w, f.w) + cross(a.v, f.v), cross(a.w, f.v)); }        // motion x* force
+template <class T> LM_DEV SVT<T> sv(V3T<T> w, V3T<T> v) { SVT<T> r; r.w = w; r.v = v; return r; }
+template <class T> LM_DEV SVT<T> operator+(SVT<T> a, SVT<T> b) { return sv(a.w + b.w, a.v + b.v); }
+template <class T> LM_DEV SVT<T> operator-(SVT<T> a, SVT<T> b) { return sv(a.w - b.w, a.v - b.v); }
+template <class T> LM_DEV SVT<T> operator*(T s, SVT<T> a) { return sv(s * a.w, s * a.v); }
+template <class T> LM_DEV SVT<T> fma6(T s, SVT<T> a, SVT<T> b) { return sv(fma3(s, a.w, b.w), fma3(s, a.v, b.v)); }
+template <class T> LM_DEV T sdot(SVT<T> a, SVT<T> b) { return dot(a.w, b.w) + dot(a.v, b.v); }
+template <class T> LM_DEV SVT<T> mcross(SVT<T> a, SVT<T> b) { return sv(cross(a.w, b.w), cross(a.w, b.v) + cross(a.v, b.w)); }        // motion x motion
+template <class T> LM_DEV SVT<T> fcross(SVT<T> a, SVT<T> f) { return sv(cross(a.w, f.w) + cross(a.v, f.v), cross(a.w, f.v)); }        // motion x* force
 // unit revolute axis through point o with direction z: [z; o x z]
-LM_DEV SV axis_sv(V3 z, V3 o) { return sv(z, cross(o, z)); }
+template <class T> LM_DEV SVT<T> axis_sv(V3T<T> z, V3T<T> o) { return sv(z, cross(o, z)); }
+LM_DEV SVP bc(SV a) { return sv(bc(a.w), bc(a.v)); }
+LM_DEV SV lo(SVP a) { return sv(lo(a.w), lo(a.v)); }
+LM_DEV SV hi(SVP a) { return sv(hi(a.w), hi(a.v)); }
 
-LM_DEV V3 symmul(const SI& I, V3 w) {
-  return v3(I.xx * w.x + I.xy * w.y + I.xz * w.z, I.xy * w.x + I.yy * w.y + I.yz * w.z, I.xz * w.x + I.yz * w.y + I.zz * w.z);
+template <class T> LM_DEV V3T<T> symmul(const SIT<T>& I, V3T<T> w) {
+  return v3t<T>(I.xx * w.x + I.xy * w.y + I.xz * w.z, I.xy * w.x + I.yy * w.y + I.yz * w.z, I.xz * w.x + I.yz * w.y + I.zz * w.z);
 }
-LM_DEV SV operator*(const SI& I, SV x) { return sv(symmul(I, x.w) + cross(I.h, x.v), fma3(I.m, x.v, cross(x.w, I.h))); }
-LM_DEV SI operator+(const SI& a, const SI& b) {
-  SI r; r.m = a.m + b.m; r.h = a.h + b.h; r.xx = a.xx + b.xx; r.yy = a.yy + b.yy; r.zz = a.zz + b.zz;
+template <class T> LM_DEV SVT<T> operator*(const SIT<T>& I, SVT<T> x) { return sv(symmul(I, x.w) + cross(I.h, x.v), fma3(I.m, x.v, cross(x.w, I.h))); }
+template <class T> LM_DEV SIT<T> operator+(const SIT<T>& a, const SIT<T>& b) {
+  SIT<T> r; r.m = a.m + b.m; r.h = a.h + b.h; r.xx = a.xx + b.xx; r.yy = a.yy + b.yy; r.zz = a.zz + b.zz;
   r.xy = a.xy + b.xy; r.xz = a.xz + b.xz; r.yz = a.yz + b.yz; return r;
 }
+LM_DEV SI lo(const SIP& a) { SI r; r.m = a.m.x; r.h = lo(a.h); r.xx = a.xx.x; r.yy = a.yy.x; r.zz = a.zz.x; r.xy = a.xy.x; r.xz = a.xz.x; r.yz = a.yz.x; return r; }
+LM_DEV SI hi(const SIP& a) { SI r; r.m = a.m.y; r.h = hi(a.h); r.xx = a.xx.y; r.yy = a.yy.y; r.zz = a.zz.y; r.xy = a.xy.y; r.xz = a.xz.y; r.yz = a.yz.y; return r; }
 // body inertia (m, com in body frame, I about COM in body axes [xx,yy,zz,xy,xz,yz]) placed at pose (R,o) -> about O
-LM_DEV SI place_inertia(const float* t, const M3& R, V3 o) {
-  float m = t[0];
-  V3 c = o + mul(R, v3(t[1], t[2], t[3]));
+template <class T> LM_DEV SIT<T> place_inertia(const T* t, const M3T<T>& R, V3T<T> o) {
+  T m = t[0];
+  V3T<T> c = o + mul(R, v3t<T>(t[1], t[2], t[3]));
   // T = R * Ib (Ib symmetric), Iw = T * R^T
-  V3 t0 = fma3(t[4], R.c0, fma3(t[7], R.c1, t[8] * R.c2));   // T col0 = R * Ib col0 = xx*c0 + xy*c1 + xz*c2
-  V3 t1 = fma3(t[7], R.c0, fma3(t[5], R.c1, t[9] * R.c2));   // xy, yy, yz
-  V3 t2 = fma3(t[8], R.c0, fma3(t[9], R.c1, t[6] * R.c2));   // xz, yz, zz
+  V3T<T> t0 = fma3(t[4], R.c0, fma3(t[7], R.c1, t[8] * R.c2));   // T col0 = R * Ib col0 = xx*c0 + xy*c1 + xz*c2
+  V3T<T> t1 = fma3(t[7], R.c0, fma3(t[5], R.c1, t[9] * R.c2));   // xy, yy, yz
+  V3T<T> t2 = fma3(t[8], R.c0, fma3(t[9], R.c1, t[6] * R.c2));   // xz, yz, zz
   // Iw[i][j] = sum_k T[i][k] R[j][k]
-  SI I; I.m = m; I.h = m * c;
-  float cc = dot(c, c);
+  SIT<T> I; I.m = m; I.h = m * c;
+  T cc = dot(c, c);
   I.xx = t0.x * R.c0.x + t1.x * R.c1.x + t2.x * R.c2.x + m * (cc - c.x * c.x);
   I.yy = t0.y * R.c0.y + t1.y * R.c1.y + t2.y * R.c2.y + m * (cc - c.y * c.y);
   I.zz = t0.z * R.c0.z + t1.z * R.c1.z + t2.z * R.c2.z + m * (cc - c.z * c.z);

@@ -139,14 +139,23 @@ class RLTask:
         return (torch.empty((N, self.num_observations), device=dev), torch.empty((N, 93), device=dev), torch.empty((N,), device=dev),
                 torch.empty((N,), dtype=torch.int64, device=dev), torch.empty((13,), device=dev))
 
+    def _extras_layout(self):
+        """(key, index into the 13-float extras block) pairs of this task, built once."""
+        lay = getattr(self, "_extras_layout_cache", None)
+        if lay is None:
+            lay = [(k, i) for i, k in enumerate(EXTRAS_KEYS)]
+            if self.split_env() is not None:
+                lay += [(k, 8 + i) for i, k in enumerate(COTRAIN_EXTRAS_KEYS)]
+            if getattr(self, "custom_controller", False):
+                lay += [(k, 10 + i) for i, k in enumerate(self.cc_extras_keys)]
+            self._extras_layout_cache = lay
+        return lay
+
     def extras_dict(self, extras) -> Dict[str, torch.Tensor]:
-        """The 13-float extras block of a step as the reference's `extras` dict (quadruped_pose_control.py:560,610,633)."""
-        d = {k: extras[i] for i, k in enumerate(EXTRAS_KEYS)}
-        if self.split_env() is not None:
-            d.update({k: extras[8 + i] for i, k in enumerate(COTRAIN_EXTRAS_KEYS)})
-        if getattr(self, "custom_controller", False):
-            d.update({k: extras[10 + i] for i, k in enumerate(self.cc_extras_keys)})
-        return d
+        """The 13-float extras block of a step as the reference's `extras` dict of 0-d tensors (quadruped_pose_control.py:560,610,633);
+        one unbind instead of one indexing op per key: this runs on every step() of the boundary."""
+        parts = extras.unbind(0)
+        return {k: parts[i] for k, i in self._extras_layout()}
 
     def state_dict(self):
         """Simulator checkpoint (engine state, counters, success windows, randomisation counters); see lib.Engine.state_dict."""
@@ -172,7 +181,8 @@ class RLTask:
     def fused_step(self, actions: torch.Tensor):
         """pre_physics_step + controlFrequencyInv x world.step + post_physics_step in one launch
         (vec_env_rlgames.py:56-79).  Returned tensors are freshly allocated and clipped."""
-        actions = actions.to(self._device, dtype=torch.float32).contiguous()
+        if actions.dtype != torch.float32 or str(actions.device) != str(self._device) or not actions.is_contiguous():
+            actions = actions.to(self._device, dtype=torch.float32).contiguous()
         self.current_actions = actions
         out = self._alloc_outputs()
         self.engine.step(actions, self._goal_rand(), *out)

@@ -18,7 +18,9 @@ Supported entries (everything the reference's YAMLs enable):
     articulation_views.<robot>.damping                 "   (the viscous joint damping of the PD-actuator tasks; no effect on velocity-drive tasks,
                                                            whose joint_damping is 0)
     articulation_views.<robot>.joint_friction          accepted and ignored with a warning (joint friction itself is not modelled)
-Anything else (scale, mass, density, material_properties, stiffness ...) raises NotImplementedError when
+    articulation_views.<robot>.scale on_startup        accepted with a warning: factors drawn and recorded, not applied (see
+                                                       apply_on_startup_domain_randomization: the reference's call does not rescale the links either)
+Anything else (mass, density, material_properties, stiffness ...) raises NotImplementedError when
 `randomize: True` - a silently ignored randomisation would be worse than a loud one."""
 from __future__ import annotations
 
@@ -65,6 +67,7 @@ class Randomizer:
         self._channels: List[DRChannel] = [DRChannel() for _ in range(DR_CHANNELS)]
         self._observations_dr_params = None
         self._actions_dr_params = None
+        self.startup_scales = dict()          # (group, view) -> per-env factors drawn by apply_on_startup_domain_randomization
         dr_config = self._cfg.get("domain_randomization", None)
         if dr_config is not None:
             randomize = dr_config.get("randomize", False)
@@ -75,16 +78,52 @@ class Randomizer:
 
     # ------------------------------------------------------------------ reference entry points
     def apply_on_startup_domain_randomization(self, task):
-        """randomize.py:58-117: scale / mass / density on_startup.  A model-table change, not a per-step quantity: not supported."""
+        """randomize.py:58-117: scale / mass / density on_startup.
+
+        `articulation_views.<robot>.scale` is the one on_startup entry the reference's YAMLs carry (cfg/task/QuadrupedPoseControl.yaml:167-172,
+        uniform [0.98, 1.02]).  In the reference it calls `view.set_local_scales` on the articulation root, which its authors note does not
+        scale the robot ("checked; but not scaling the entire robot?", :110 of that YAML): the link geometry, inertias and joint frames PhysX
+        simulates are unchanged.  Here the entry is therefore ACCEPTED: the per-env factors are drawn as the reference draws them (one
+        synchronised factor per env, torch generator seeded with the config seed, randomize.py:60,308-350) and kept in `startup_scales`
+        for inspection, a warning says that they do not enter the dynamics, and the compiled model table stays shared by all envs.
+        mass / density on_startup entries would change that table per env and are refused."""
         if not self.randomize:
             return
+        import warnings
+        import torch
         params = self._cfg["domain_randomization"]["randomization_params"]
         for group in ("rigid_prim_views", "articulation_views"):
             for view, attrs in (params.get(group) or {}).items():
                 for attribute, entry in (attrs or {}).items():
-                    if entry is not None and "on_startup" in entry:
+                    if entry is None or "on_startup" not in entry:
+                        continue
+                    st = entry["on_startup"]
+                    if not set(_ON_RESET_KEYS).issubset(st.keys()):          # randomize.py:75-77,104-106
+                        raise ValueError(f"Please ensure the following randomization parameters for {view} {attribute} on_startup are provided: "
+                                         "operation, distribution, distribution_parameters.")
+                    if attribute != "scale":
                         raise NotImplementedError(f"domain randomisation of {group}.{view}.{attribute} on_startup is not implemented "
-                                                  "(robot scale / mass / density change the compiled model table)")
+                                                  "(mass / density change the compiled model table per env)")
+                    n = int(self._cfg["env"]["numEnvs"])
+                    g = torch.Generator().manual_seed(int(self._config.get("seed", 42)))
+                    lo, hi = (float(x) for x in st["distribution_parameters"])
+                    dist = str(st["distribution"])
+                    if dist == "uniform":
+                        f = lo + (hi - lo) * torch.rand(n, generator=g)
+                    elif dist in ("loguniform", "log_uniform"):
+                        f = torch.exp(np.log(lo) + (np.log(hi) - np.log(lo)) * torch.rand(n, generator=g))
+                    elif dist in ("gaussian", "normal"):
+                        f = lo + hi * torch.randn(n, generator=g)
+                    else:
+                        raise ValueError(f"{view} scale on_startup: unsupported distribution {dist!r}")
+                    op = str(st["operation"])
+                    if op not in ("scaling", "additive", "direct"):
+                        raise ValueError(f"{view} scale on_startup: unsupported operation {op!r}")
+                    self.startup_scales[(group, view)] = (1.0 * f) if op in ("scaling", "direct") else (1.0 + f)
+                    self.active_domain_randomizations[(group, view, attribute, "on_startup")] = np.array(st["distribution_parameters"])
+                    warnings.warn(f"{group}.{view}.scale on_startup: accepted; the factors ({lo}..{hi}) are drawn and kept in "
+                                  "Randomizer.startup_scales but do not enter the dynamics (in the reference set_local_scales on the articulation "
+                                  "root does not rescale the simulated links either)")
 
     def set_up_domain_randomization(self, task):
         """randomize.py:125-166: walk the YAML block; here it fills the engine's channel table."""

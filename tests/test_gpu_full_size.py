@@ -1,0 +1,110 @@
+"""BASELINE.json configs 3, 4 (its per-GPU block) and 5 at their REAL sizes, through size-independent properties
+(config 2 is tests/test_gpu_parity.py::test_full_size_invariants_4096; the oracle comparisons run at 16-256 envs).
+
+  config 3  QuadrupedManipulatePlate, 4096 envs: plate-pose sanity on top of the generic invariants
+  config 4  JointLocomanipulation, 2048 locomotion + 2048 manipulation envs per GPU: per-half extras and success windows
+  config 5  JointLocomanipulationVertical, 8192 envs with the GNN policy in the loop (48-step fused rollouts)
+
+Invariants: finite state / outputs, unit quaternions, clipped observations, reward inside the reference's assert window (> -50,
+quadruped_pose_control.py:556-558) and below bonus + best orientation reward, counters inside their ranges, returned resets == reset_buf,
+extras == means of the per-env terms (the fused cross-wavefront reduction is complete), resets do occur, no contained blow-up.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def generic_invariants(task, out, half=None):
+    obs_d, rew, resets, extras = out
+    e = task.engine; s = e.state; c = e.cnt
+    obs = obs_d["obs"]
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(s).all()
+    assert obs.abs().max() <= 5.0 and float(rew.min()) > -50 and float(rew.max()) < 610
+    assert (s[86:90].norm(dim=0) - 1).abs().max() < 1e-5                                        # goal quaternions
+    assert int(c[4].max()) <= int(task._max_episode_length) - 1 and int(c[4].min()) >= 1 and int(c[1].max()) <= 17 and int(c[1].min()) >= 0
+    assert torch.equal(resets, c[3]) and set(torch.unique(c[3]).tolist()) <= {0, 1}
+    tm = e.terms[:7].double().mean(dim=1)
+    ex = torch.stack([extras[k] for k in list(extras)[:7]]).double()
+    assert (ex - tm).abs().max() < 1e-5 * max(1.0, float(tm.abs().max()))
+    assert e.blowups == 0
+
+
+def test_config3_manipulation_4096():
+    import locomanipulationrl_amd as lm
+    N = 4096
+    env = lm.make_env("QuadrupedManipulatePlate", num_envs=N, seed=42)
+    env.reset(); task = env._task
+    g = torch.Generator(device="cuda").manual_seed(42)
+    total = 0
+    for t in range(300):
+        out = env.step(torch.rand(N, 12, device="cuda", generator=g) * 2 - 1)
+        total += int(out[2].sum())
+        if t % 50 == 49:
+            generic_invariants(task, out)
+            s = task.engine.state
+            assert (s[40:44].norm(dim=0) - 1).abs().max() < 1e-5                                # plate quaternion
+            # the plate stays near the inverted robot: an env whose plate slides off or is thrown resets (plate-frame height tests,
+            # quadruped_manipulate_plate.py:576-603) before it can leave this box
+            assert float(s[37:39].abs().max()) < 0.6 and float(s[39].min()) > -0.05 and float(s[39].max()) < 0.6
+            assert float(s[44:50].abs().max()) < 50.0
+            assert (task.plate_pos_ground - s[37:40].T).abs().max() == 0                        # the reference-named views are the engine's memory
+    assert total > 0
+    env.close()
+
+
+def test_config4_cotrain_block_2048_2048():
+    import locomanipulationrl_amd as lm
+    N = 4096; h = N // 2
+    env = lm.make_env("JointLocomanipulation", num_envs=N, seed=42)
+    obs = env.reset(); task = env._task
+    assert obs["obs"].shape == (N, 64) and obs["states"].data_ptr() == obs["obs"].data_ptr()   # states alias obs (joint_locomanipulation.py:548)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    res_l = res_m = 0
+    for t in range(300):
+        out = env.step(torch.rand(N, 12, device="cuda", generator=g) * 2 - 1)
+        res_l += int(out[2][:h].sum()); res_m += int(out[2][h:].sum())
+        if t % 50 == 49:
+            generic_invariants(task, out)
+            s = task.engine.state
+            assert (s[3:7, :h].norm(dim=0) - 1).abs().max() < 1e-5 and (s[40:44, h:].norm(dim=0) - 1).abs().max() < 1e-5
+            # locomotion half: bases near their drop point; manipulation half: plates above the inverted robots fixed at z 0.5
+            assert float(s[2, :h].min()) > 0.0 and float(s[2, :h].max()) < 0.3 and float(s[39, h:].min()) > 0.3 and float(s[39, h:].max()) < 1.0
+            ex = out[3]
+            for k in ("env/success_rate", "env/success_rate_loco", "env/success_rate_mani"):
+                assert 0.0 <= float(ex[k]) <= 1.0
+            st = task.engine.stats_i64          # {successes, resets} x {all, first half, second half}: three windows, each emptied on its own
+            assert all(0 <= int(st[2 * k]) <= int(st[2 * k + 1]) <= 2048 + N for k in range(3))      # when it passes 2048 resets (joint_locomanipulation.py:795-830)
+    assert res_l > 0 and res_m > 0
+    env.close()
+
+
+def test_config5_vertical_gnn_8192_rollout():
+    import locomanipulationrl_amd as lm
+    from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params
+    N, T = 8192, 48
+    env = lm.make_env("JointLocomanipulationVertical", num_envs=N, seed=42)
+    first = env.reset(); task = env._task
+    torch.manual_seed(42)
+    pol = GraphPolicy().cuda()
+    ro = task.make_rollout("gnn", pack_gnn_params(pol.net, pol.mean_layer, pol.value_layer).cuda(), torch.full((12,), -0.7, device="cuda"), T, noise_seed=1)
+    ro.obs[0].copy_(first["obs"])
+    resets = 0
+    for it in range(6):
+        ro.run("auto"); torch.cuda.synchronize()
+        assert torch.isfinite(ro.obs).all() and torch.isfinite(ro.actions).all() and torch.isfinite(ro.rewards).all() and torch.isfinite(ro.values).all()
+        assert ro.obs.abs().max() <= 5.0 and float(ro.rewards.min()) > -50 and float(ro.rewards.max()) < 610
+        assert set(torch.unique(ro.dones).tolist()) <= {0, 1}
+        resets += int(ro.dones.sum())
+        # the policy really is in the loop: actions are the GNN's gaussian samples (not constant, inside a few sigma of a bounded mean)
+        assert float(ro.actions.std()) > 0.1 and float(ro.actions.abs().max()) < 50
+        with torch.no_grad():
+            mean, _, _ = pol(ro.obs[3].clamp(-5, 5))
+        assert float((ro.actions[3] - mean).std()) == pytest.approx(float(np.exp(-0.7)), rel=0.05)
+        e = task.engine; s = e.state; h = N // 2
+        assert torch.isfinite(s).all() and (s[3:7, :h].norm(dim=0) - 1).abs().max() < 1e-5 and (s[40:44, h:].norm(dim=0) - 1).abs().max() < 1e-5
+        assert int(e.cnt[4].max()) <= 299 and e.blowups == 0
+        ro.obs[0].copy_(ro.obs[T])
+    assert resets > 0
+    ro.close(); env.close()

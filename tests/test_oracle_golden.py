@@ -131,12 +131,24 @@ def test_quat_from_euler_and_rand_quaternions(robot_model):
         assert np.abs(q - g["rand_quat"][i]).max() < 1e-6
 
 
-def test_take_action_scaling():
+def test_take_action_scaling(robot_model):
+    """RobotOmni.take_action (robot.py:444-461), golden = the reference's own method for its three control modes.  Velocity mode is what
+    every task on the path uses: the oracle's drive must pull the joints to exactly the golden targets (in free flight with an
+    unsaturated drive the implicit servo lands on its target in one sub-step).  The other two scalings are checked on the host mirror
+    RobotOmni classes expose them through (unscale_transform with +-pi / +-torque limit)."""
+    from dataclasses import replace
+    from locomanipulationrl_amd.utils.math import unscale_transform
+    import torch
     g = np.load(os.path.join(GOLDEN, "take_action.npz"))
-    a = g["actions"]
-    assert np.allclose(g["velocity"], a * 3.0, atol=1e-6)          # robot.py:452-454 (the mode every task uses)
-    assert np.allclose(g["position"], a * np.float32(np.pi), atol=1e-6)
-    assert np.allclose(g["effort"][:, :12], a * 1.5, atol=1e-6) and np.all(g["effort"][:, 12:] == 0)
+    a = g["actions"].astype(np.float64)
+    ep = replace(loco_params(), gravity=0.0, tau_max=1e12, kd=1e6)      # a stiff, unsaturated servo: lands on its target up to I / (dt kd)
+    o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(a.shape[0]); o.reset(phys, task, cnt); phys[:, 2] = 5.0
+    o.substep(phys, a * ep.act_scale)                       # lmo_step scales the clamped action by act_scale (= velocity_limits 3.0) like :452-454
+    assert np.abs(phys[:, 25:37] - g["velocity"]).max() < 1e-5
+    at = torch.from_numpy(g["actions"])
+    assert np.allclose(unscale_transform(at, torch.tensor(-np.pi), torch.tensor(np.pi)).numpy(), g["position"], atol=1e-6)
+    assert np.allclose(unscale_transform(at, torch.tensor(-1.5), torch.tensor(1.5)).numpy(), g["effort"][:, :12], atol=1e-6) and np.all(g["effort"][:, 12:] == 0)
 
 
 def test_hash_rng_is_uniform_and_deterministic(robot_model):

@@ -75,48 +75,59 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
+# ---- the 7 third-party quaternion helpers (omni.isaac.core.utils.torch.rotations; source absent) with the semantics the reference's
+# call sites fix: scalar-first, Hamilton product, quat_rotate_inverse(q, v) = R(q)^T v, quat_axis(q, k) = R(q) e_k,
+# euler 'xyz' = Rz(yaw) Ry(pitch) Rx(roll).  Module level so that tests/test_math_host.py can check them against scipy.
+def quat_mul(a, b):
+    w1, x1, y1, z1 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    w2, x2, y2, z2 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+                        w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+def quat_conjugate(a):
+    return torch.cat((a[..., :1], -a[..., 1:]), dim=-1)
+
+def quat_rotate(q, v):
+    qw, qv = q[:, 0:1], q[:, 1:]
+    return v * (2.0 * qw ** 2 - 1.0) + torch.cross(qv, v, dim=-1) * qw * 2.0 + qv * (qv * v).sum(-1, keepdim=True) * 2.0
+
+def quat_rotate_inverse(q, v):
+    qw, qv = q[:, 0:1], q[:, 1:]
+    return v * (2.0 * qw ** 2 - 1.0) - torch.cross(qv, v, dim=-1) * qw * 2.0 + qv * (qv * v).sum(-1, keepdim=True) * 2.0
+
+def quat_axis(q, axis=0):
+    b = torch.zeros(q.shape[0], 3, device=q.device, dtype=q.dtype)
+    b[:, axis] = 1
+    return quat_rotate(q, b)
+
+def quat_apply(q, v):
+    return quat_rotate(q, v)
+
+def quat_from_euler_xyz(roll, pitch, yaw):
+    cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
+    cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
+    cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
+    return torch.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp,
+                        cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp], dim=-1)
+
+
+def unscale_transform(x, lower, upper):
+    return x * (upper - lower) * 0.5 + (upper + lower) * 0.5
+
+
+STANDIN_HELPERS = (quat_mul, quat_conjugate, quat_rotate, quat_rotate_inverse, quat_axis, quat_apply, quat_from_euler_xyz)
+
+
 def _install_placeholders():
     sys.meta_path.insert(0, _Finder())
     rot = types.ModuleType("omni.isaac.core.utils.torch.rotations")
 
-    def quat_mul(a, b):
-        w1, x1, y1, z1 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
-        w2, x2, y2, z2 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
-        return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
-                            w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
-                            w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
-                            w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
-
-    def quat_conjugate(a):
-        return torch.cat((a[..., :1], -a[..., 1:]), dim=-1)
-
-    def quat_rotate(q, v):
-        qw, qv = q[:, 0:1], q[:, 1:]
-        return v * (2.0 * qw ** 2 - 1.0) + torch.cross(qv, v, dim=-1) * qw * 2.0 + qv * (qv * v).sum(-1, keepdim=True) * 2.0
-
-    def quat_rotate_inverse(q, v):
-        qw, qv = q[:, 0:1], q[:, 1:]
-        return v * (2.0 * qw ** 2 - 1.0) - torch.cross(qv, v, dim=-1) * qw * 2.0 + qv * (qv * v).sum(-1, keepdim=True) * 2.0
-
-    def quat_axis(q, axis=0):
-        b = torch.zeros(q.shape[0], 3, device=q.device, dtype=q.dtype)
-        b[:, axis] = 1
-        return quat_rotate(q, b)
-
-    def quat_apply(q, v):
-        return quat_rotate(q, v)
-
-    def quat_from_euler_xyz(roll, pitch, yaw):
-        cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
-        cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
-        cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
-        return torch.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp,
-                            cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp], dim=-1)
-
-    for f in (quat_mul, quat_conjugate, quat_rotate, quat_rotate_inverse, quat_axis, quat_apply, quat_from_euler_xyz):
+    for f in STANDIN_HELPERS:
         setattr(rot, f.__name__, f)
     maths = types.ModuleType("omni.isaac.core.utils.torch.maths")
-    maths.unscale_transform = lambda x, lower, upper: x * (upper - lower) * 0.5 + (upper + lower) * 0.5
+    maths.unscale_transform = unscale_transform
     import omni.isaac.core.utils.torch  # noqa: F401  (placeholder package)
     sys.modules[rot.__name__] = rot
     sys.modules[maths.__name__] = maths
