@@ -34,10 +34,9 @@ ENVS_PER_GPU = 4096
 ROLLOUT = 48
 BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (460 read + 1028 written)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP32_PEAK_TFLOPS = 157.3           # vector fp32 peak
 # rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE / flop counters, tools/profile_round.sh): counters cannot be
 # collected from inside the run, so `roofline.traffic` and `valu.flop_per_env_step` are READ FROM the newest of these files and labelled so
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc_v6.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json",)]
 
 
 def _omp_threads(n):
@@ -205,7 +204,7 @@ def main():
         pmc_file = next((f for f in PMC_FILES if os.path.exists(f)), None)
         pmc = json.load(open(pmc_file)) if pmc_file else None
         traffic = pmc["per_launch"]["hbm_traffic_bytes"] if pmc else None
-        flop_env = pmc["flop_per_env_step"] if pmc else None
+        wave = (pmc or {}).get("wave")
         pmc_src = ("read from " + os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of this command; not collected in this run)") if pmc else None
         value = world * N * args.steps / elapsed
         # second protocol of SURVEY 8(d): zero actions (standing robots, only the 300-step timeout resets); rank 0, untimed region
@@ -259,10 +258,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step", "kernel_ms": k_avg_ms, "kernel_ms_median": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
-            "valu": None if flop_env is None else {
-                "achieved": flop_env * N / (k_avg_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": flop_env * N / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "waves_per_launch": N * 4 // 64,
-                "flop_per_env_step": flop_env, "flop_source": pmc_src},
+            # one wavefront per SIMD at 4096 envs: the binding resource is the wavefront's own instruction stream (fp32 VALU issue slots +
+            # exposed latency), reported from the PMC passes; `step_quad_cycles` = this run's kernel time in quad-cycles at 2.4 GHz
+            "valu": None if wave is None else dict(wave, waves_per_launch=N * 4 // 64, simds=1024,
+                                                   step_quad_cycles=k_avg_ms * 1e-3 * 2.4e9 / 4, source=pmc_src),
         }
     eng.close()
     if world > 1:

@@ -1749,4 +1749,5 @@ int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs) {
   return (policy == LM_POLICY_MLP && (nobs == 64 || nobs == LM_MAX_OBS)) || (policy == LM_POLICY_GNN && nobs == 64);
 }
 
+uint32_t lm_internal_seed(const lm_engine* h) { return h ? h->seed : 0u; }
 int lm_internal_fail(int code, const char* msg) { return fail(code, msg); }

@@ -198,6 +198,7 @@ class Engine:
             rc = self.lib.lm_create(C.byref(self._h), self.num_envs, table.ctypes.data_as(C.c_void_p), arr, len(params),
                                     int(split_env or 0), C.c_uint32(seed))
         self._check(rc)
+        self.seed = int(seed) & 0xFFFFFFFF
         N = self.num_envs
         self.state = self._wrap(PTR_STATE, (STATE_ROWS, N), "<f4")
         self.cnt = self._wrap(PTR_CNT, (CNT_ROWS, N), "<i8")
@@ -294,6 +295,7 @@ class Engine:
 
     def set_seed(self, seed: int):
         self._check(self.lib.lm_set_seed(self._h, C.c_uint32(seed)))
+        self.seed = int(seed) & 0xFFFFFFFF
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -335,12 +337,14 @@ class Engine:
         """Everything lm_step reads besides its arguments: SoA state, counters, success windows, randomisation counters (host tensors)."""
         self.torch.cuda.synchronize(self.device)
         return {"state": self.state.cpu().clone(), "cnt": self.cnt.cpu().clone(), "stats": self._stats_i32.cpu().clone(),
-                "dr_cnt": self.dr_cnt.cpu().clone(), "num_envs": self.num_envs}
+                "dr_cnt": self.dr_cnt.cpu().clone(), "num_envs": self.num_envs, "seed": self.seed}
 
     def load_state_dict(self, sd):
         assert int(sd["num_envs"]) == self.num_envs and tuple(sd["state"].shape) == tuple(self.state.shape)
         self.state.copy_(sd["state"].to(self.device)); self.cnt.copy_(sd["cnt"].to(self.device))
         self._stats_i32.copy_(sd["stats"].to(self.device)); self.dr_cnt.copy_(sd["dr_cnt"].to(self.device))
+        if "seed" in sd:          # goal sampling / domain randomisation are keyed by the seed: a resumed engine must carry the checkpoint's
+            self.set_seed(int(sd["seed"]))
 
 
 POLICY_MLP, POLICY_GNN = 0, 1

@@ -22,8 +22,11 @@ if __name__ == "__main__":
             elif k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY"): pw[k + "_quad"] = round(v, 1)
             else: pw[k] = round(v, 1)
         fetch = per_wave.get("FETCH_SIZE", 0.0) * 1024 * waves; write = per_wave.get("WRITE_SIZE", 0.0) * 1024 * waves
+        # fp32 VALU instruction counters: a packed instruction (v_pk_fma_f32 ...) does two lanes' worth of arithmetic per lane but is ONE
+        # instruction, so this is a LOWER bound of the flops since round 2 (the step kernel issues about a third of its fp32 work packed)
         flop = (per_wave.get("SQ_INSTS_VALU_ADD_F32", 0) + per_wave.get("SQ_INSTS_VALU_MUL_F32", 0) + per_wave.get("SQ_INSTS_VALU_TRANS_F32", 0)
                 + 2 * per_wave.get("SQ_INSTS_VALU_FMA_F32", 0)) * 64 / 16          # per-lane ops of a 64-lane wavefront holding 16 envs
+        wc, wa, vi = per_wave.get("SQ_WAVE_CYCLES", 0.0), per_wave.get("SQ_WAIT_ANY", 0.0), per_wave.get("SQ_INSTS_VALU", 0.0)
         print(json.dumps({
             "source": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), bench.py --steps 100 --warmup 20, k_step dispatches only, "
                       f"4096 envs = {waves} wavefronts per launch (tools/profile_round.sh)",
@@ -31,7 +34,12 @@ if __name__ == "__main__":
             "per_launch": {"fetch_bytes": fetch, "write_bytes": write, "hbm_traffic_bytes": fetch + write,
                            "note": "FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950 (the guide's x2 correction applies to 16 B/lane streams only); "
                                    "writes include the unclipped obs_buf/states_buf copies the API exposes (+628 B/env) and the per-env reward terms (+44 B/env)"},
-            "flop_per_env_step": flop}, indent=1))
+            "wave": {"valu_instructions": round(vi, 1), "wave_quad_cycles": round(wc, 1), "wait_quad_cycles": round(wa, 1),
+                     "valu_issue_fraction": round(vi / wc, 4) if wc else None, "wait_fraction": round(wa / wc, 4) if wc else None,
+                     "note": "one wavefront per SIMD: a VALU instruction occupies one quad-cycle issue slot, so valu_issue_fraction is the share of the "
+                             "wavefront's lifetime spent issuing vector arithmetic"},
+            "flop_per_env_step_lower_bound": flop,
+            "flop_note": "packed fp32 instructions are counted once by SQ_INSTS_VALU_*_F32"}, indent=1))
     else:
         for d in sys.argv[1:]:
             pw, waves = collect(d)
