@@ -43,7 +43,12 @@
 #define LM_ITAB_FLOATS (HUB_FLOATS + 4 * LIMB_STRIDE)
 static void permute_table(const float* pub, float* dev) {
   memset(dev, 0, LM_ITAB_FLOATS * sizeof(float));
-  for (int i = 0; i < HUB_FLOATS; i++) dev[i] = pub[i];
+  {   // hub body: (m, com, I about COM) -> spatial inertia about the hub origin (m, h = m c, I_O [xx,yy,zz,xy,xz,yz]), constant in hub coordinates
+    const double m = pub[0], c[3] = {pub[1], pub[2], pub[3]}, cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    dev[0] = (float)m; dev[1] = (float)(m * c[0]); dev[2] = (float)(m * c[1]); dev[3] = (float)(m * c[2]);
+    dev[4] = (float)(pub[4] + m * (cc - c[0] * c[0])); dev[5] = (float)(pub[5] + m * (cc - c[1] * c[1])); dev[6] = (float)(pub[6] + m * (cc - c[2] * c[2]));
+    dev[7] = (float)(pub[7] - m * c[0] * c[1]); dev[8] = (float)(pub[8] - m * c[0] * c[2]); dev[9] = (float)(pub[9] - m * c[1] * c[2]);
+  }
   for (int l = 0; l < 4; l++) {
     const float* s = pub + HUB_FLOATS + l * PUB_LIMB_STRIDE; float* d = dev + HUB_FLOATS + l * LIMB_STRIDE;
     for (int k = 0; k < 13; k++) { d[T_J0 + k] = s[k]; d[T_P1 + 2 * k] = s[13 + k]; d[T_P1 + 2 * k + 1] = s[39 + k]; d[T_P2 + 2 * k] = s[26 + k]; d[T_P2 + 2 * k + 1] = s[52 + k]; }
@@ -139,12 +144,9 @@ LM_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
 LM_DEV M3 load_m3_rowmajor(const float* t) {
   M3 R; R.c0 = v3(t[0], t[3], t[6]); R.c1 = v3(t[1], t[4], t[7]); R.c2 = v3(t[2], t[5], t[8]); return R;
 }
-// hub body: table holds (m, com, I about COM) in the hub frame -> spatial inertia about the hub origin
-LM_DEV SI hub_inertia(const float* t) {
-  M3 I; I.c0 = v3(1, 0, 0); I.c1 = v3(0, 1, 0); I.c2 = v3(0, 0, 1);
-  return place_inertia(t, I, v3(0, 0, 0));
-}
 LM_DEV SI load_si(const float* t) { SI I; I.m = t[0]; I.h = v3(t[1], t[2], t[3]); I.xx = t[4]; I.yy = t[5]; I.zz = t[6]; I.xy = t[7]; I.xz = t[8]; I.yz = t[9]; return I; }
+// hub body: the device table holds its spatial inertia about the hub origin (permute_table)
+LM_DEV SI hub_inertia(const float* t) { return load_si(t); }
 LM_DEV void si_to_66(const SI& I, float A[6][6]) {
   A[0][0] = I.xx; A[0][1] = I.xy; A[0][2] = I.xz; A[1][1] = I.yy; A[1][2] = I.yz; A[2][2] = I.zz;
   A[1][0] = I.xy; A[2][0] = I.xz; A[2][1] = I.yz;
@@ -291,7 +293,7 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // cross blocks X_K = T_i^T B_K towards the other three contacts; lanes take turns, the lane whose turn it is
 // relaxes its three rows, then its three impulse increments are quad-broadcast and every other lane updates c
 // with 9 FMAs.  Identical arithmetic (up to rounding) to row-wise PGS on the dense 12x12 system of the oracle.
-struct PgsData { float Wf[6]; float rW[3]; float X[4][9]; };      // X[K]: this contact's 3x3 block towards contact K (K == own limb: the own block)
+struct PgsData { float Wf[6]; float rW[3]; f2 Xp[4][3]; float Xs[4][3]; };      // this contact's 3x3 block towards contact K (K == own limb: the own block), by columns s: Xp[K][s] = (X[0][s] | X[1][s]), Xs[K][s] = X[2][s]
 
 // ---- "four 6-vectors at once" layout of the pass linear algebra.  Component i of the vectors (v0, v1, v2, v3) is an R4: p = (v0[i] | v1[i]),
 // q = (v2[i] | v3[i]), so that an operation applied to all four is two packed-fp32 instructions and any single entry is a free half-register
@@ -344,7 +346,7 @@ LM_DEV void chol6_solve4(const Chol6& C, R4 x[6]) {
 
 // 3x3 block of this lane's contact rows T_i against the B vectors of contact K:  X[3 r + s] = T_i,r . B_K,s  (K == own limb: the own block)
 template <int K>
-LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float Wf[6], float Xo[9]) {
+LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float Wf[6], f2 Xp[3], float Xs[3]) {
   f2 a0 = sp2(0.f), a1 = sp2(0.f), a2 = sp2(0.f); float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
@@ -354,32 +356,31 @@ LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float
     a0 = fma_(sp2(t0), k12, a0); a1 = fma_(sp2(t1), k12, a1); a2 = fma_(sp2(t2), k12, a2);
   }
   const bool own = (limb == K);
-  Xo[0] = own ? Wf[0] : b0;   Xo[1] = own ? Wf[1] : a0.x; Xo[2] = own ? Wf[2] : a0.y;
-  Xo[3] = own ? Wf[1] : b1;   Xo[4] = own ? Wf[3] : a1.x; Xo[5] = own ? Wf[4] : a1.y;
-  Xo[6] = own ? Wf[2] : b2;   Xo[7] = own ? Wf[4] : a2.x; Xo[8] = own ? Wf[5] : a2.y;
+  // rows r = 0, 1, 2 of the block; column s = 0 from the b's, columns 1 and 2 from the a's
+  Xp[0] = mk2(own ? Wf[0] : b0, own ? Wf[1] : b1);     Xs[0] = own ? Wf[2] : b2;
+  Xp[1] = mk2(own ? Wf[1] : a0.x, own ? Wf[3] : a1.x); Xs[1] = own ? Wf[4] : a2.x;
+  Xp[2] = mk2(own ? Wf[2] : a0.y, own ? Wf[4] : a1.y); Xs[2] = own ? Wf[5] : a2.y;
 }
 
 // One Gauss-Seidel turn: contact K relaxes its rows n, t1, t2 in sequence (each row sees the rows before it through the two
 // temporaries t1, t2), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies
 // c += X[K] * d.  Lanes whose turn it is not run the same instructions on their own (discarded) candidates; only `lam` is guarded.
 template <int K>
-LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float lam[3], float c[3]) {
+LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float lam[3], f2& c01, float& c2) {
   const bool mine = (limb == K);
-  const float ln = fmaxf(0.0f, fmaf(-c[0], G.rW[0], lam[0]));
+  const float ln = fmaxf(0.0f, fmaf(-c01.x, G.rW[0], lam[0]));
   const float d0 = ln - lam[0];
   const float lim = mu * ln;
-  const float t1 = fmaf(G.Wf[1], d0, c[1]);
+  const float t1 = fmaf(G.Wf[1], d0, c01.y);
   const float l1 = __builtin_amdgcn_fmed3f(fmaf(-t1, G.rW[1], lam[1]), -lim, lim);
   const float d1 = l1 - lam[1];
-  const float t2 = fmaf(G.Wf[4], d1, fmaf(G.Wf[2], d0, c[2]));
+  const float t2 = fmaf(G.Wf[4], d1, fmaf(G.Wf[2], d0, c2));
   const float l2 = __builtin_amdgcn_fmed3f(fmaf(-t2, G.rW[2], lam[2]), -lim, lim);
   const float d2 = l2 - lam[2];
   lam[0] = mine ? ln : lam[0]; lam[1] = mine ? l1 : lam[1]; lam[2] = mine ? l2 : lam[2];
   const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d1), b2 = quad_bcast<K>(d2);
-  const float* X = G.X[K];
-  c[0] = fmaf(X[0], b0, fmaf(X[1], b1, fmaf(X[2], b2, c[0])));
-  c[1] = fmaf(X[3], b0, fmaf(X[4], b1, fmaf(X[5], b2, c[1])));
-  c[2] = fmaf(X[6], b0, fmaf(X[7], b1, fmaf(X[8], b2, c[2])));
+  c01 = fma_(G.Xp[K][0], sp2(b0), fma_(G.Xp[K][1], sp2(b1), fma_(G.Xp[K][2], sp2(b2), c01)));
+  c2 = fmaf(G.Xs[K][0], b0, fmaf(G.Xs[K][1], b1, fmaf(G.Xs[K][2], b2, c2)));
 }
 
 // T[i].p.y, T[i].q = this lane's three contact rows (hub / plate wrench per unit impulse); X[i].p.y, X[i].q = B = Phi T
@@ -398,22 +399,22 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
     G.Wf[3] = Wl[3] + a1.x; G.Wf[4] = Wl[4] + a1.y; G.Wf[5] = Wl[5] + a2.y;
   }
   G.rW[0] = 1.0f / G.Wf[0]; G.rW[1] = 1.0f / G.Wf[3]; G.rW[2] = 1.0f / G.Wf[5];
-  pgs_cross_blocks<0>(limb, T, X, G.Wf, G.X[0]); pgs_cross_blocks<1>(limb, T, X, G.Wf, G.X[1]);
-  pgs_cross_blocks<2>(limb, T, X, G.Wf, G.X[2]); pgs_cross_blocks<3>(limb, T, X, G.Wf, G.X[3]);
+  pgs_cross_blocks<0>(limb, T, X, G.Wf, G.Xp[0], G.Xs[0]); pgs_cross_blocks<1>(limb, T, X, G.Wf, G.Xp[1], G.Xs[1]);
+  pgs_cross_blocks<2>(limb, T, X, G.Wf, G.Xp[2], G.Xs[2]); pgs_cross_blocks<3>(limb, T, X, G.Wf, G.Xp[3], G.Xs[3]);
   lam[0] = lam[1] = lam[2] = 0.f;
-  float c[3] = {vf[0] + bn, vf[1], vf[2]};
+  f2 c01 = mk2(vf[0] + bn, vf[1]); float c2 = vf[2];
   // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
   // ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
   for (int it = 0; it < iters; it += 2) {
-    pgs_turn<0>(limb, mu, G, lam, c);
-    pgs_turn<1>(limb, mu, G, lam, c);
-    pgs_turn<2>(limb, mu, G, lam, c);
-    pgs_turn<3>(limb, mu, G, lam, c);
+    pgs_turn<0>(limb, mu, G, lam, c01, c2);
+    pgs_turn<1>(limb, mu, G, lam, c01, c2);
+    pgs_turn<2>(limb, mu, G, lam, c01, c2);
+    pgs_turn<3>(limb, mu, G, lam, c01, c2);
     if (it + 1 < iters) {
-      pgs_turn<3>(limb, mu, G, lam, c);
-      pgs_turn<2>(limb, mu, G, lam, c);
-      pgs_turn<1>(limb, mu, G, lam, c);
-      pgs_turn<0>(limb, mu, G, lam, c);
+      pgs_turn<3>(limb, mu, G, lam, c01, c2);
+      pgs_turn<2>(limb, mu, G, lam, c01, c2);
+      pgs_turn<1>(limb, mu, G, lam, c01, c2);
+      pgs_turn<0>(limb, mu, G, lam, c01, c2);
     }
   }
   // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
@@ -913,10 +914,20 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     if (W.out_obs) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
       reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NO)[i] = v; }
   }
-  for (int i = lane; i < nenv * 93; i += 64) {
-    float v = sSt[i];
-    W.states_buf[(size_t)env0 * 93 + i] = v;
-    if (W.out_states) W.out_states[(size_t)env0 * 93 + i] = clampf(v, clip);
+  // states: 16 rows of 93 floats are one contiguous block of 372 float4 (env0 is a multiple of 16: 5952-byte offsets)
+  if (nenv == ENVS_PER_WAVE && (reinterpret_cast<uintptr_t>(W.out_states) & 15) == 0) {
+    for (int i = lane; i < ENVS_PER_WAVE * 93 / 4; i += 64) {
+      float4 v = reinterpret_cast<const float4*>(sSt)[i];
+      reinterpret_cast<float4*>(W.states_buf + (size_t)env0 * 93)[i] = v;
+      if (W.out_states) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
+        reinterpret_cast<float4*>(W.out_states + (size_t)env0 * 93)[i] = v; }
+    }
+  } else {
+    for (int i = lane; i < nenv * 93; i += 64) {
+      float v = sSt[i];
+      W.states_buf[(size_t)env0 * 93 + i] = v;
+      if (W.out_states) W.out_states[(size_t)env0 * 93 + i] = clampf(v, clip);
+    }
   }
   if (active && limb == 0) {
     W.rew_buf[env] = O.rew;

@@ -1,6 +1,6 @@
 """Where k_step's time goes (4096 envs, loco): the runtime parameters switch phases off, so the differences are phase costs.
     substeps 4 -> 1 : per-sub-step cost and the fixed part (load, reset, task layer, outputs)
-    pgs_iters 8 -> 0 : the contact solver sweeps;  tau_max -> huge : no saturated joints => the second active-set pass never runs"""
+    pgs_iters 8 -> 0 : the contact solver sweeps;  tau_max 180.7 -> 1.5 : round 1's torque clamp, under which most sub-steps run the second active-set pass"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,7 @@ def run(N, steps=400, warmup=50, **kw):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    cases = {"default": {}, "pgs0": dict(pgs_iters=0), "nosat": dict(tau_max=1e9), "nosat_pgs0": dict(tau_max=1e9, pgs_iters=0),
-             "sub1": dict(substeps=1), "sub1_nosat_pgs0": dict(substeps=1, tau_max=1e9, pgs_iters=0), "sub8": dict(substeps=8)}
+    cases = {"default": {}, "pgs0": dict(pgs_iters=0), "torque_clamp_1.5": dict(tau_max=1.5), "torque_clamp_1.5_pgs0": dict(tau_max=1.5, pgs_iters=0),
+             "sub1": dict(substeps=1), "sub1_pgs0": dict(substeps=1, pgs_iters=0), "sub8": dict(substeps=8)}
     res = {k: run(N, **v) for k, v in cases.items()}
     print(json.dumps({"envs": N, "us_per_step": res}))
