@@ -815,6 +815,7 @@ LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
 struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms; float *out_obs, *out_states, *out_rew; int64_t* out_resets;
                  long long* acc;          // int64 [16]: fixed-point sums of the 12 per-env terms, first-task shares of goal_reset / reset, -, arrival ticket
                  char* stats; float* extras; float* out_extras; int split_block; };
+#define LM_ACC_COPIES 32         // accumulator rows the per-wavefront sums of a launch are spread over (write_outputs); power of two
 #define ACC_SCALE 1048576.0f      // 2^20: integer accumulation makes the means independent of the arrival order (bitwise reproducible)
 
 LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
@@ -824,9 +825,20 @@ LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t a
 }
 
 // Totals of one step -> extras (means of the reward terms, success-rate windows); clears the accumulators.  One wavefront.
-LM_DEV void finalize_extras(const lm_params* __restrict__ P, const OutPtrs& W, int N, int lane) {
+// spread: the partial sums were added to LM_ACC_COPIES accumulator rows behind row 0 (write_outputs); they are summed and cleared here -
+// integer addition, so the totals do not depend on the order.
+LM_DEV void finalize_extras(const lm_params* __restrict__ P, const OutPtrs& W, int N, int lane, bool spread = false) {
   long long tot = 0;
-  if (lane < 14) tot = __hip_atomic_load(W.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (spread) {
+    long long* sl = W.acc + 16;
+    const int k = lane & 15;                      // entry of the row; lane >> 4 = which of four rows per load
+    long long v[LM_ACC_COPIES / 4];
+#pragma unroll
+    for (int i = 0; i < LM_ACC_COPIES / 4; i++) v[i] = __hip_atomic_load(sl + (size_t)(4 * i + (lane >> 4)) * 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < LM_ACC_COPIES / 4; i++) { tot += v[i]; __hip_atomic_store(sl + (size_t)(4 * i + (lane >> 4)) * 16 + k, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    tot += __shfl_xor(tot, 16); tot += __shfl_xor(tot, 32);
+  } else if (lane < 14) tot = __hip_atomic_load(W.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
   if (lane < 7) { float m = sum / (float)N; W.extras[lane] = m; if (W.out_extras) W.out_extras[lane] = m; }
   if (lane >= 9 && lane < 12) { float m = sum / (float)N; W.extras[lane + 1] = m; if (W.out_extras) W.out_extras[lane + 1] = m; }      // extras 10..12
@@ -889,7 +901,11 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     for (int k = 0; k < 12; k++) { tot0[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part[k]))); mine = (lane == k) ? tot0[k] : mine; }   // lane 0 holds the sums
     mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
     mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
-    if (lane < 14) dummy = __hip_atomic_fetch_add(W.acc + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // 256 wavefronts adding to the same 14 addresses serialise 3600 read-modify-writes on one cache line (3.5 us of a 39 us step):
+    // the adds are spread over LM_ACC_COPIES accumulator rows (row = block index mod copies), which the last wavefront sums.  The
+    // per-step rows of the persistent rollout kernel (DEFER) are single rows: its blocks drift apart in time.
+    long long* row = DEFER ? W.acc : W.acc + 16 + (size_t)(blockIdx.x & (LM_ACC_COPIES - 1)) * 16;
+    if (lane < 14) dummy = __hip_atomic_fetch_add(row + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const float clip = P->clip_obs;
   int nenv = min(ENVS_PER_WAVE, N - env0);
@@ -944,7 +960,7 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     int ticket = 0;
     if (lane == 0) ticket = (int)__hip_atomic_fetch_add(W.acc + 15, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0);
-    if (ticket == (int)gridDim.x - 1) finalize_extras(P, W, N, lane);
+    if (ticket == (int)gridDim.x - 1) finalize_extras(P, W, N, lane, true);
   } else {
     asm volatile("" :: "v"(dummy));
   }
@@ -1587,7 +1603,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_rew, N * sizeof(float));
   ALLOC(h->d_extras, 16 * sizeof(float));
   ALLOC(h->d_terms, LM_TERM_ROWS * N * sizeof(float));
-  ALLOC(h->d_acc, 16 * sizeof(long long));
+  ALLOC(h->d_acc, (16 + (size_t)LM_ACC_COPIES * 16) * sizeof(long long));      // row 0: ticket (+ totals of the legacy path); rows 1..: spread accumulators
   ALLOC(h->d_stats, 64);
 #undef ALLOC
   float itab[LM_ITAB_FLOATS]; permute_table(table, itab);      // public packed layout -> the device's chain-interleaved layout
