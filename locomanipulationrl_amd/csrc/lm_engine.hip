@@ -1107,7 +1107,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
       substep<MODE, VAR, DR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc, X);
     }
   }
-  // ---- task-layer state
+  // ---- task-layer state (loaded after the physics: issuing these loads at the top of the last sub-step was measured and gains nothing)
   TaskState S; int episode; float lqd[3];
   S.succ = (int)cnt[0 * (size_t)N + env]; S.consec = (int)cnt[1 * (size_t)N + env]; S.greset = (int)cnt[2 * (size_t)N + env];
   S.reset = (int)cnt[3 * (size_t)N + env]; S.progress = (int)cnt[4 * (size_t)N + env]; episode = (int)cnt[5 * (size_t)N + env];
@@ -1289,6 +1289,7 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
 // at a time, the window counters live in registers across the steps; same arithmetic as finalize_extras
 __global__ void __launch_bounds__(64) k_rollout_finalize(const lm_params* params, OutPtrs W, int N, long long* acc_steps, float* extras, int T) {
   __shared__ long long sAcc[64 * 16];
+  __shared__ int sCnt[64 * 4];          // per step: goal resets, resets (all envs), goal resets, resets (first task)
   const int lane = threadIdx.x;
   int64_t* ns_g = reinterpret_cast<int64_t*>(W.stats); float* rate_g = reinterpret_cast<float*>(W.stats + 48);
   int64_t ns[6]; float rate[3];
@@ -1299,24 +1300,37 @@ __global__ void __launch_bounds__(64) k_rollout_finalize(const lm_params* params
   const int64_t max_cnt = (int64_t)params->max_reset_counts;
   for (int k0 = 0; k0 < T; k0 += 64) {
     const int nk = min(64, T - k0);
-    for (int i = lane; i < nk * 16; i += 64) {
-      sAcc[i] = __hip_atomic_load(acc_steps + 16 * (size_t)k0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(acc_steps + 16 * (size_t)k0 + i, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      // all 16 loads of a lane in flight at once (they bypass the L2: issued one by one, each was a full round trip), then the clears
+      long long v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; v[j] = (i < nk * 16) ? __hip_atomic_load(acc_steps + 16 * (size_t)k0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0LL; }
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < nk * 16) { sAcc[i] = v[j]; __hip_atomic_store(acc_steps + 16 * (size_t)k0 + i, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < nk; k++) {
-      const bool last = (k0 + k == T - 1);
-      float* ex = extras ? extras + (size_t)(k0 + k) * LM_NUM_EXTRAS : nullptr;
-      const long long tot = (lane < 14) ? sAcc[16 * k + lane] : 0;
-      const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
-      if (lane < 7) { float m = sum / (float)N; if (last) W.extras[lane] = m; if (ex) ex[lane] = m; }
-      if (lane >= 9 && lane < 12) { float m = sum / (float)N; if (last) W.extras[lane + 1] = m; if (ex) ex[lane + 1] = m; }
-      const float gsf = __shfl(sum, 7), rsf = __shfl(sum, 8), glf = __shfl(sum, 12), rlf = __shfl(sum, 13);
-      const int64_t gs = (int64_t)(gsf + 0.5f), rs = (int64_t)(rsf + 0.5f), gl = (int64_t)(glf + 0.5f), rl = (int64_t)(rlf + 0.5f);
-      success_window(ns + 0, rate + 0, gs, rs, max_cnt);
-      success_window(ns + 2, rate + 1, gl, rl, max_cnt);
-      success_window(ns + 4, rate + 2, gs - gl, rs - rl, max_cnt);
-      if (lane == 0) {
+    // the means of a step do not depend on the other steps: one lane per step (same arithmetic as finalize_extras)
+    if (lane < nk) {
+      const bool last = (k0 + lane == T - 1);
+      float* ex = extras ? extras + (size_t)(k0 + lane) * LM_NUM_EXTRAS : nullptr;
+#pragma unroll
+      for (int j = 0; j < 14; j++) {
+        const float sum = (float)((double)sAcc[16 * lane + j] * (1.0 / (double)ACC_SCALE));
+        if (j < 7) { const float m = sum / (float)N; if (last) W.extras[j] = m; if (ex) ex[j] = m; }
+        else if (j >= 9 && j < 12) { const float m = sum / (float)N; if (last) W.extras[j + 1] = m; if (ex) ex[j + 1] = m; }
+        else sCnt[4 * lane + (j == 7 ? 0 : j == 8 ? 1 : j == 12 ? 2 : 3)] = (int)(sum + 0.5f);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+    // the success-rate windows are a recurrence over the steps: one lane walks them in order
+    if (lane == 0) {
+      for (int k = 0; k < nk; k++) {
+        const bool last = (k0 + k == T - 1);
+        float* ex = extras ? extras + (size_t)(k0 + k) * LM_NUM_EXTRAS : nullptr;
+        const int64_t gs = sCnt[4 * k], rs = sCnt[4 * k + 1], gl = sCnt[4 * k + 2], rl = sCnt[4 * k + 3];
+        success_window(ns + 0, rate + 0, gs, rs, max_cnt);
+        success_window(ns + 2, rate + 1, gl, rl, max_cnt);
+        success_window(ns + 4, rate + 2, gs - gl, rs - rl, max_cnt);
 #pragma unroll
         for (int c = 0; c < 3; c++) { if (last) W.extras[7 + c] = rate[c]; if (ex) ex[7 + c] = rate[c]; }
       }
