@@ -1275,7 +1275,8 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
     }
     if (k == R.T) break;
     if (t < 64) {
-      // (the sampled actions, the counters and the state are written and read back by this same wavefront: program order, no wait needed)
+      // (the counters and the state are written and read back by this same wavefront: program order.  The sampled actions too with the MLP;
+      // the GNN tile stores them from all four wavefronts and drains those stores before its closing barrier, lm_policy_dev.h gnn_body)
       B.actions = SA.actions; B.goal_rand = nullptr;
       B.W.out_obs = R.obs + (size_t)(k + 1) * Nk * NOBS; B.W.out_states = nullptr; B.W.out_rew = R.rewards + (size_t)k * Nk;
       B.W.out_resets = R.dones + (size_t)k * Nk; B.W.out_extras = nullptr; B.W.acc = R.acc_steps + 16 * k;

@@ -386,6 +386,10 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
   // value head: max over all nodes = max over the four wavefronts' partial maxima
 #pragma unroll
   for (int i = 0; i < 4; i++) { sHm[((WAVE * 32) + 4 * g + i) * GNN_SAMPLES + n] = hm0[i]; sHm[((WAVE * 32) + 16 + 4 * g + i) * GNN_SAMPLES + n] = hm1[i]; }
+  // Persistent rollout (observations in LDS): the sampled actions were stored to global memory by ALL FOUR wavefronts and are read back by
+  // wavefront 0's physics step right after this barrier.  lds_barrier() orders LDS traffic only, so the stores are drained first
+  // (vmcnt(0): written through to the L2 the block's loads are served from); nothing else is in flight at this point of the tile.
+  if (LDS_OBS && SA.log_std) __builtin_amdgcn_s_waitcnt(0x0F70);
   lds_barrier();
   if (WAVE != 0) return;
   float v = 0.f;
