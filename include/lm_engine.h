@@ -53,6 +53,7 @@ enum { LM_DR_OBS_RESET = 0, LM_DR_OBS_INTERVAL = 1, LM_DR_ACT_RESET = 2, LM_DR_A
        LM_DR_GRAVITY = 4, LM_DR_BASE_FORCE = 5, LM_DR_MAX_EFFORT = 6, LM_DR_MAX_VELOCITY = 7,
        LM_DR_JOINT_DAMPING = 8 /* articulation `damping` of the PD-actuator tasks (variants 1 / 2): scales joint_damping */ };
 enum { LM_DR_ADDITIVE = 0, LM_DR_SCALING = 1, LM_DR_DIRECT = 2 };
+enum { LM_DRIVE_VELOCITY = 0, LM_DRIVE_POSITION = 1, LM_DRIVE_EFFORT = 2 };
 enum { LM_DR_GAUSSIAN = 0, LM_DR_UNIFORM = 1, LM_DR_LOGUNIFORM = 2 };
 typedef struct lm_dr_channel {
   int32_t enabled;
@@ -91,6 +92,10 @@ typedef struct lm_params {
   int32_t dr_enabled;        /* domain_randomization.randomize */
   int32_t dr_min_frequency;  /* domain_randomization.min_frequency: gate of the on_reset physics attributes (quadruped_pose_control.py:224-228) */
   lm_dr_channel dr[LM_DR_CHANNELS];
+  int32_t drive_mode;        /* variant 0 only - RobotOmni.take_action's control modes (robot/base/robot.py:444-461):
+                                LM_DRIVE_VELOCITY  target = a * act_scale [rad/s]           implicit damper kd (the mode every task of the path uses)
+                                LM_DRIVE_POSITION  target = a * act_scale [rad] (act_scale = pi); tau = pd_kp (q* - q) - kd qd, re-evaluated per sub-step
+                                LM_DRIVE_EFFORT    tau = a * act_scale [N m] (act_scale = torque limit), gains off */
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */

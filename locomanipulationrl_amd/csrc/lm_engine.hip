@@ -545,7 +545,9 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     }
   }
 
-  bool sat[3] = {false, false, false}; float tsat[3] = {0.f, 0.f, 0.f};
+  // effort mode (RobotOmni.take_action, robot.py:455-459): tgt IS the joint torque, gains off = the constant-torque branch from the start
+  const bool effort = (VAR == 0) && P->drive_mode == LM_DRIVE_EFFORT;
+  bool sat[3] = {effort, effort, effort}; float tsat[3] = {effort ? tgt[0] : 0.f, effort ? tgt[1] : 0.f, effort ? tgt[2] : 0.f};
   float qdn[3]; SV un;
   for (int pass = 0; pass < 2; pass++) {
     asm volatile("" ::: "memory");          // keep the stash reloads inside the pass (no hoisting across the PGS loop)
@@ -668,6 +670,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
 #undef LM_WROW
     }
     if (pass == 0) {
+      if (effort) break;
       int any = 0;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -1083,8 +1086,14 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
   if (!pd) {
     // ---- take_action (robot.py:452-454): velocity targets
-    float tgt[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
-    for (int s = 0; s < nsub; s++) substep<MODE, VAR, DR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc, X);
+    // velocity mode (every task of the path): the drive's velocity target; effort mode: the torque; position mode (robot.py:448-450):
+    // q* = a * act_scale, tau = kp (q* - q) - kd qd = kd (v* - qd) with v* = kp / kd (q* - q), re-evaluated every sub-step
+    const float a0[3] = {act[0] * P->act_scale, act[1] * P->act_scale, act[2] * P->act_scale};
+    const bool posm = P->drive_mode == LM_DRIVE_POSITION; const float gp = posm ? P->pd_kp / P->kd : 0.f;
+    for (int s = 0; s < nsub; s++) {
+      const float tgt[3] = {posm ? gp * (a0[0] - q[0]) : a0[0], posm ? gp * (a0[1] - q[1]) : a0[1], posm ? gp * (a0[2] - q[2]) : a0[2]};
+      substep<MODE, VAR, DR>(P, sTab, tl, limb, St, F, Rfix, pfix, q, qd, tgt, tau_acc, X);
+    }
   } else {
     // ---- custom-controller tasks (quadruped_pose_control_custom_controller.py:255-307): the action integrates the swing / extension
     // position targets; the actuator torque  clamp(kp (q* - q) - kd qd, +-tau_max)  is re-evaluated every sub-step.  It is the same drive
@@ -1579,6 +1588,8 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     const lm_params& p = params[t];
     if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
       return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
+    if (p.drive_mode < 0 || p.drive_mode > 2 || (p.drive_mode != 0 && p.variant != 0) || (p.drive_mode == LM_DRIVE_POSITION && !(p.kd > 0)))
+      return fail(LM_EINVAL, "lm_create: drive_mode must be 0 (velocity), 1 (position: kd > 0) or 2 (effort), and 0 for the PD-actuator variants");
     if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || p.variant < 0 || p.variant > 2 ||
         (p.variant == 1) != (p.num_obs == LM_MAX_OBS) || (p.variant >= 1 && !(p.kd > 0 && p.torque_div > 0 && p.acc_substeps >= 1 && p.acc_substeps <= p.substeps)))
       return fail(LM_EINVAL, "lm_create: invalid variant / num_obs (64 for velocity-drive and position-control tasks, 88 for custom-controller tasks, equal across tasks) or acc_substeps");

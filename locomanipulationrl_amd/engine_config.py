@@ -29,6 +29,7 @@ from typing import List
 
 MODE_LOCO = 0    # free base on a ground plane
 MODE_MANI = 1    # fixed (inverted) base + free plate
+DRIVE_VELOCITY, DRIVE_POSITION, DRIVE_EFFORT = 0, 1, 2
 
 
 def _f(x):
@@ -140,6 +141,9 @@ class EngineParams:
     dr_enabled: int = 0
     dr_min_frequency: int = 1
     dr: List[DRChannel] = field(default_factory=_no_dr)
+    # ---- RobotOmni.take_action control mode (robot/base/robot.py:444-461), variant 0 only: 0 velocity (every task of the path), 1 position
+    # (target a * act_scale rad with act_scale = pi, PD gains pd_kp / kd), 2 effort (torque a * act_scale N m with act_scale = torque limit)
+    drive_mode: int = 0
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 

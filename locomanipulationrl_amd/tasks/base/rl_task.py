@@ -192,6 +192,8 @@ class RLTask:
     def pre_physics_step(self, actions: torch.Tensor) -> None:
         if self._dr_randomizer.randomize:
             raise NotImplementedError("domain randomisation is sampled inside the fused lm_step launch; use env.step() when randomize is True")
+        if self.engine_params()[0].drive_mode == 1:
+            raise NotImplementedError("position control re-evaluates its PD torque every sub-step inside the fused launch; use env.step()")
         if getattr(self, "custom_controller", False):
             raise NotImplementedError("the custom-controller tasks run their physics inside pre_physics_step in the reference "
                                       "(…custom_controller.py:285-296); use env.step() (fused) for them")

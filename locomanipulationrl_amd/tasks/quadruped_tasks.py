@@ -80,8 +80,8 @@ class _QuadrupedTask(RLTask):
         else:
             mu = mu_body
         rd = robot.robot_description
-        if rd.control_mode != "velocity" and not getattr(self, "custom_controller", False):
-            raise NotImplementedError("only the velocity drive and the custom PD controller are implemented")
+        if rd.control_mode not in ("velocity", "position", "effort"):          # robot.py:323-333
+            raise AttributeError(f"Invalid control mode name {rd.control_mode!r}")
         lo1, hi1 = self.min_joint_1_pos, self.max_joint_1_pos
         rlo1, rhi1 = self.reset_min_joint_1_pos, self.reset_max_joint_1_pos
         if self.mirrored_dof1_limits:
@@ -100,7 +100,7 @@ class _QuadrupedTask(RLTask):
             tau_lim = tau_lim / float(sim["dt"])
         base = dict(
             dt=float(sim["dt"]), substeps=int(self.control_frequency_inv), pgs_iters=int(eng.get("pgs_iters", 8)), gravity=float(-g[2]),
-            kd=float(rd.joint_kds[0]), tau_max=tau_lim, act_scale=float(rd.velocity_limits[0]), mu=mu,
+            kd=float(rd.joint_kds[0]), tau_max=tau_lim, act_scale=float(rd.velocity_limits[0]), mu=mu, drive_mode=0,
             tip_radius=float(eng.get("tip_radius", 0.005)), baumgarte=float(eng.get("baumgarte", 0.2)),
             max_depen_vel=float(eng.get("max_depenetration_velocity", 1.0)),
             max_joint_vel=float(eng.get("max_joint_velocity_deg", 450.0)) * 3.141592653589793 / 180.0,
@@ -116,6 +116,15 @@ class _QuadrupedTask(RLTask):
             d1_pen=d1_pen, d1_rst=d1_rst, h_base=float(self.baseline_height), h_corner=float(self.baseline_corner_height),
             h_knee=float(self.baseline_knee_height), corner=[list(c) for c in self.corner_points],
         )
+        if not getattr(self, "custom_controller", False) and rd.control_mode != "velocity":
+            # RobotOmni.take_action's other two modes (robot.py:444-461): position targets a * pi against the PD gains of the robot
+            # description (robot_description.py:37-41), or joint efforts a * torque limit with the gains off (switch_control_mode)
+            if rd.control_mode == "position":
+                if not float(rd.joint_kds[0]) > 0:
+                    raise ValueError("position control needs joint_kds > 0 (the drive is solved as kd (kp/kd (q* - q) - qd))")
+                base.update(drive_mode=1, act_scale=3.141592653589793, pd_kp=float(rd.joint_kps[0]))
+            else:
+                base.update(drive_mode=2, act_scale=float(rd.torque_limits[0]))
         if getattr(self, "custom_controller", False):      # quadruped_pose_control_custom_controller.py:24-52,88-97
             v = int(self.controller_variant)
             base.update(variant=v, num_obs=88 if v == 1 else 64, acc_substeps=int(self.control_frequency_inv), kd=float(self.control_kd), pd_kp=float(self.control_kp), joint_damping=float(self.joint_damping),

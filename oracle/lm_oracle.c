@@ -347,7 +347,9 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
       Jc[3*i][a]=jn; Jc[3*i+1][a]=j1; Jc[3*i+2][a]=j2; }
     if (phi>=0) bn[i]=phi/dt; else { real b=(real)p->baumgarte*phi/dt; if (b<-(real)p->max_depen_vel) b=-(real)p->max_depen_vel; bn[i]=b; }
   }
-  int sat[12]; real tsat[12]; for (int j=0;j<12;j++){sat[j]=0;tsat[j]=0;}
+  /* effort mode (robot.py:455-459): the action is the joint torque itself, gains off - the constant-torque branch of the drive from the start */
+  const int effort = (p->variant==0 && p->drive_mode==2);
+  int sat[12]; real tsat[12]; for (int j=0;j<12;j++){sat[j]=effort;tsat[j]=effort?target[j]:0;}
   real un[NU];
   for (int pass=0; pass<2; pass++) {
     real L[NU][NU]; memcpy(L, D->M, sizeof(L)); real rhs[NU];
@@ -370,7 +372,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
     if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];
-    if (pass==0) { int any=0; for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
+    if (pass==0) { int any=0; if (!effort) for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
       if (!any) break; }
   }
   if (tau_out) for (int j=0;j<12;j++) tau_out[j] = sat[j] ? tsat[j] : kd*(target[j]-un[6+j]);   /* drive torque applied over this sub-step */
@@ -578,6 +580,15 @@ static void step_core(const lmo_model* m, const lmo_params* p, int N, real* phys
   if (p->variant==0) {
     /* robot.py:452-454: velocity mode, unscale_transform(a, -lim, +lim) = a*lim */
     for (size_t i=0;i<(size_t)N*12;i++) targets[i]=actions[i]*(real)p->act_scale;
+    if (p->drive_mode==1) {
+      /* position mode (robot.py:448-450): q* = a * pi; tau = kp (q* - q) - kd qd = kd (v* - qd) with v* = kp/kd (q* - q), refreshed every sub-step */
+      real* vt=(real*)malloc(sizeof(real)*12*(size_t)N);
+      for (int s=0;s<p->substeps;s++) {
+        for (int e=0;e<N;e++) for (int i=0;i<12;i++) vt[(size_t)e*12+i]=(real)p->pd_kp/(real)p->kd*(targets[(size_t)e*12+i]-phys[(size_t)e*LMO_PHYS+13+i]);
+        substeps_all(m, p, N, phys, vt, NULL, drs);
+      }
+      free(vt);
+    } else
     for (int s=0;s<p->substeps;s++) substeps_all(m, p, N, phys, targets, NULL, drs);
   } else {
     /* quadruped_pose_control_custom_controller.py:255-307: integrate swing/extension targets, PD torque every sub-step */

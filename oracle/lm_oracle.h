@@ -134,6 +134,9 @@ typedef struct {
    * max efforts, max joint velocities; their sampling lives in omni.replicator.isaac, absent: this repo's specification) */
   int32_t dr_enabled, dr_min_frequency;
   lmo_dr_channel dr[LMO_DR_CHANNELS];
+  int32_t drive_mode;        /* variant 0: RobotOmni.take_action's control mode (robot/base/robot.py:444-461): 0 velocity target a*act_scale,
+                                1 position target a*act_scale with tau = pd_kp (q* - q) - kd qd per sub-step, 2 effort tau = a*act_scale */
+  int32_t pad1;
 } lmo_params;
 
 /* per-env physical state, env-major */

@@ -178,10 +178,15 @@ def test_task_layer_against_reference_golden(robot_model, engine_cls, kind):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_full_step_parity_from_identical_states(robot_model, engine_cls, oracle_cls, mode):
-    """mode 2/3: the custom-controller variants (PD actuator on swing/extension targets, 88-wide observation); 4/5: position control."""
-    ep = [loco_params, mani_params, loco_cc_params, mani_cc_params, loco_pc_params, mani_pc_params][mode]()
+    """mode 2/3: the custom-controller variants (PD actuator on swing/extension targets, 88-wide observation); 4/5: position control;
+    6/7/8: RobotOmni.take_action's position and effort control modes (robot.py:444-461) on the locomotion / manipulation scenes."""
+    import math
+    ep = [loco_params, mani_params, loco_cc_params, mani_cc_params, loco_pc_params, mani_pc_params,
+          lambda: loco_params(drive_mode=1, act_scale=math.pi, pd_kp=5.0, kd=1.0),          # robot_description.py:37-41 gains
+          lambda: loco_params(drive_mode=2, act_scale=1.5),
+          lambda: mani_params(drive_mode=2, act_scale=1.5)][mode]()
     N = 256; o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N, seed=42)
     rng = np.random.default_rng(5)
     phys, task, cnt = o.new_state(N)

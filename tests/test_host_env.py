@@ -253,3 +253,38 @@ def test_custom_controller_dr_config_runs_randomised():
     assert not ep.dr[DR_OBS_RESET].enabled and env._task.randomize_actions and not env._task.randomize_observations
     env.reset(); o, r, d, _ = env.step(torch.zeros(16, 12)); assert o["obs"].shape == (16, 88) and torch.isfinite(o["obs"]).all()
     assert make("QuadrupedPoseControlCustomControllerDR", 16)._task.engine_params()[0].dr_enabled == 0          # off by default, as in the reference
+
+
+def test_position_and_effort_control_modes_through_the_wrapper():
+    """robot_description.control_mode = "position" / "effort" (robot/base/robot.py:323-333,444-461) reach the engine as drive modes."""
+    import math
+    from locomanipulationrl_amd.tasks.quadruped_tasks import QuadrupedPoseControl
+
+    class PosTask(QuadrupedPoseControl):
+        def __init__(self, sim_config, name="QuadrupedPoseControl", env=None, offset=None):
+            super().__init__(sim_config, name, env, offset)
+            rd = self.robot_locomotion.robot_description
+            rd.control_mode = "position"; rd.joint_kps = [5, 5, 5] * 4; rd.joint_kds = [1, 1, 1] * 4
+
+    class EffTask(QuadrupedPoseControl):
+        def __init__(self, sim_config, name="QuadrupedPoseControl", env=None, offset=None):
+            super().__init__(sim_config, name, env, offset)
+            self.robot_locomotion.robot_description.control_mode = "effort"
+
+    from locomanipulationrl_amd.utils import task_util
+    for cls, dm, scale in ((PosTask, 1, math.pi), (EffTask, 2, 1.5)):
+        orig = task_util.task_map
+        task_util.task_map = lambda cls=cls, orig=orig: dict(orig(), QuadrupedPoseControl=cls)
+        try:
+            env = make("QuadrupedPoseControl", 16)
+        finally:
+            task_util.task_map = orig
+        ep = env._task.engine_params()[0]
+        assert ep.drive_mode == dm and abs(ep.act_scale - scale) < 1e-6 and (dm != 1 or (ep.pd_kp, ep.kd) == (5.0, 1.0))
+        env.reset()
+        for _ in range(3):
+            o, r, d, _ = env.step(torch.zeros(16, 12))
+        assert torch.isfinite(o["obs"]).all()
+        if dm == 1:
+            with pytest.raises(NotImplementedError):
+                env._task.pre_physics_step(torch.zeros(16, 12))

@@ -129,3 +129,36 @@ def test_saturated_drive_respects_torque_limit(robot_model):
     p2, t2, c2 = o2.new_state(1); o2.reset(p2, t2, c2); p2[0, 2] = 5.0
     o2.substep(p2, np.full((1, 12), 3.0))
     assert np.abs(p2[0, 25:37] - 3.0).max() < 0.02                             # unsaturated: servo reaches the target in one step
+
+
+def test_effort_and_position_control_modes(robot_model):
+    """RobotOmni.take_action's other two control modes (robot/base/robot.py:444-461), golden = the reference's own scaling
+    (tests/golden/take_action.npz).  Effort: the generalised force the oracle applies to the 12 driven joints is exactly the golden effort
+    (free flight, no gravity, from rest: M du/dt on the joint rows = tau).  Position: the PD drive (robot_description.py:37-41 gains
+    kp 5, kd 1) pulls every joint onto the golden position target."""
+    import math
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "take_action.npz"))
+    a = g["actions"].astype(np.float64); N = a.shape[0]
+    # ---- effort (1e-3 of the 1.5 N m scale: a full-scale torque on these links would run into the 450 deg/s joint speed limit within the sub-step)
+    ep = loco_params(drive_mode=2, act_scale=1.5e-3, gravity=0.0)
+    o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(N); o.reset(phys, task, cnt); phys[:, 2] = 5.0
+    M = [o.dyn_terms(phys[e])[0] for e in range(N)]
+    o.substep(phys, a * ep.act_scale)
+    for e in range(N):
+        R = quat2mat([1, 0, 0, 0])
+        du = np.concatenate([R.T @ phys[e, 10:13], R.T @ phys[e, 7:10], phys[e, 25:37]]) / ep.dt          # from rest: u = du
+        f = M[e] @ du
+        assert np.abs(f[6:] - 1e-3 * g["effort"][e, :12]).max() < 1e-7 and np.abs(f[:6]).max() < 5e-6, (e, np.abs(f[6:] - 1e-3 * g["effort"][e, :12]).max())
+    # ---- position (targets inside the admissible range of the loop closure: the golden targets span +-pi, scale them into +-0.4 rad about the pose)
+    ep = loco_params(drive_mode=1, act_scale=math.pi, pd_kp=5.0, kd=1.0, gravity=0.0, tau_max=1e9)
+    o = Oracle(robot_model, ep)
+    phys, task, cnt = o.new_state(N); o.step(phys, task, cnt, np.zeros((N, 12)), seed=0)
+    phys[:, 2] = 5.0; phys[:, 7:13] = 0
+    q0 = np.array(ep.init_q)
+    act = (q0 + 0.12 * g["position"].astype(np.float64)) / math.pi          # q* = init pose + 0.12 * golden position target
+    for _ in range(150):
+        phys[:, 2] = 5.0
+        o.step(phys, task, cnt, act, seed=0); cnt[:, 3] = 0
+    assert np.abs(phys[:, 13:25] - act * math.pi).max() < 2e-3, np.abs(phys[:, 13:25] - act * math.pi).max()
