@@ -82,7 +82,7 @@ struct lm_engine {
   lm_params* d_params;     // [2]
   float* d_table;
   float* d_state; int64_t* d_cnt; int64_t* d_drc; float* d_dr_phys; int dr_enabled;
-  float *d_obs, *d_states, *d_rew, *d_extras, *d_terms; long long* d_acc;
+  float *d_obs, *d_states, *d_rew, *d_extras, *d_terms; long long* d_acc; int acc_rows;
   char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48;
                            // uint32 count of contained blow-ups at byte 60
   lm_params h_params[2];
@@ -812,14 +812,30 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   if (pd && P->cc_update_last_tgt) { S.ltgt[0] = I.tgtq[0]; S.ltgt[1] = I.tgtq[1]; S.ltgt[2] = I.tgtq[2]; }      // :723-725
 }
 
+// Which 16 envs a workgroup takes.  Workgroups go round-robin to the 8 XCDs, each with its own L2, and one row of the SoA state is 64 bytes
+// per wavefront: with the identity map the two wavefronts that share a 128-byte line sit on different XCDs and both L2s fetch the whole
+// line (FETCH_SIZE showed 1.8x the bytes read; tools/microbench/fetch_calib.hip reproduces the 2x with 64-byte rows).  Within each group
+// of 16 workgroups the map puts blocks 2j and 2j+1 of envs on XCD j; the tail of a grid that is no multiple of 16 keeps the identity.
+LM_DEV int lm_block() {
+  const int b = (int)blockIdx.x;
+  return b < ((int)gridDim.x & ~15) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
+}
+
 // shared tail: write staged obs / states, reward, counters, per-block partial sums
 LM_DEV float clampf(float x, float c) { return fminf(fmaxf(x, -c), c); }
 
 struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms; float *out_obs, *out_states, *out_rew; int64_t* out_resets;
-                 long long* acc;          // int64 [16]: fixed-point sums of the 12 per-env terms, first-task shares of goal_reset / reset, -, arrival ticket
-                 char* stats; float* extras; float* out_extras; int split_block; };
-#define LM_ACC_COPIES 32         // accumulator rows the per-wavefront sums of a launch are spread over (write_outputs); power of two
+                 long long* acc;          // int64 [16 + acc_rows*16]: row 0 = totals of a launch, rows 1.. = the spread first-level rows (write_outputs);
+                                          // the persistent rollout (DEFER) points it at one plain row of 14 fixed-point sums per step
+                 char* stats; float* extras; float* out_extras; int split_block; int acc_rows; };
+#define LM_ACC_COPIES 32         // least number of first-level accumulator rows (lm_create doubles it until a row takes < 4096 wavefronts)
 #define ACC_SCALE 1048576.0f      // 2^20: integer accumulation makes the means independent of the arrival order (bitwise reproducible)
+// Counted accumulator words (k_step): bits 0..11 count the arrivals, bits 12..63 hold the sum - a signed 2^20 fixed-point value for the
+// reward-term means (words 0..6, 9..11), two unsigned 26-bit counts (goal resets | resets) for the success-rate windows (word 7 all envs,
+// 8 first task, 12 second task).  The count never carries into the sum: a word sees at most 4095 arrivals.
+#define ACC_CNT_BITS 12
+#define ACC_CNT_MASK 4095LL
+#define ACC_WIN_BITS 26
 
 LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t add_rst, int64_t max_cnt) {
   int64_t num_succ = ns[0], num_rst = ns[1]; float sr = *rate;
@@ -827,35 +843,20 @@ LM_DEV void success_window(int64_t* ns, float* rate, int64_t add_succ, int64_t a
   ns[0] = num_succ + add_succ; ns[1] = num_rst + add_rst; *rate = sr;
 }
 
-// Totals of one step -> extras (means of the reward terms, success-rate windows); clears the accumulators.  One wavefront.
-// spread: the partial sums were added to LM_ACC_COPIES accumulator rows behind row 0 (write_outputs); they are summed and cleared here -
-// integer addition, so the totals do not depend on the order.
-LM_DEV void finalize_extras(const lm_params* __restrict__ P, const OutPtrs& W, int N, int lane, bool spread = false) {
-  long long tot = 0;
-  if (spread) {
-    long long* sl = W.acc + 16;
-    const int k = lane & 15;                      // entry of the row; lane >> 4 = which of four rows per load
-    long long v[LM_ACC_COPIES / 4];
-#pragma unroll
-    for (int i = 0; i < LM_ACC_COPIES / 4; i++) v[i] = __hip_atomic_load(sl + (size_t)(4 * i + (lane >> 4)) * 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int i = 0; i < LM_ACC_COPIES / 4; i++) { tot += v[i]; __hip_atomic_store(sl + (size_t)(4 * i + (lane >> 4)) * 16 + k, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    tot += __shfl_xor(tot, 16); tot += __shfl_xor(tot, 32);
-  } else if (lane < 14) tot = __hip_atomic_load(W.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const float sum = (float)((double)tot * (1.0 / (double)ACC_SCALE));
-  if (lane < 7) { float m = sum / (float)N; W.extras[lane] = m; if (W.out_extras) W.out_extras[lane] = m; }
-  if (lane >= 9 && lane < 12) { float m = sum / (float)N; W.extras[lane + 1] = m; if (W.out_extras) W.out_extras[lane + 1] = m; }      // extras 10..12
-  const float gsf = __shfl(sum, 7), rsf = __shfl(sum, 8), glf = __shfl(sum, 12), rlf = __shfl(sum, 13);
-  if (lane == 0) {
+// The lane that completed word k of a launch publishes what depends on it: a mean of a reward term, or one success-rate window
+// (quadruped_pose_control.py:560,610,618-633; the co-train task keeps two more windows for its halves, joint_locomanipulation.py:795-859).
+// The 13 words are independent of each other, so their last arrivals may be lanes of different wavefronts.
+LM_DEV void publish_extra(const lm_params* __restrict__ P, const OutPtrs& W, int N, int k, long long tot) {
+  if (k == 7 || k == 8 || k == 12) {
+    const int w = (k == 7) ? 0 : (k == 8) ? 1 : 2;
     int64_t* ns = reinterpret_cast<int64_t*>(W.stats); float* rate = reinterpret_cast<float*>(W.stats + 48);
-    const int64_t gs = (int64_t)(gsf + 0.5f), rs = (int64_t)(rsf + 0.5f), gl = (int64_t)(glf + 0.5f), rl = (int64_t)(rlf + 0.5f);
-    success_window(ns + 0, rate + 0, gs, rs, (int64_t)P->max_reset_counts);
-    success_window(ns + 2, rate + 1, gl, rl, (int64_t)P->max_reset_counts);
-    success_window(ns + 4, rate + 2, gs - gl, rs - rl, (int64_t)P->max_reset_counts);
-#pragma unroll
-    for (int k = 0; k < 3; k++) { W.extras[7 + k] = rate[k]; if (W.out_extras) W.out_extras[7 + k] = rate[k]; }
+    success_window(ns + 2 * w, rate + w, (int64_t)(tot >> ACC_WIN_BITS), (int64_t)(tot & ((1LL << ACC_WIN_BITS) - 1)), (int64_t)P->max_reset_counts);
+    W.extras[7 + w] = rate[w]; if (W.out_extras) W.out_extras[7 + w] = rate[w];
+  } else {
+    const float m = (float)((double)tot * (1.0 / (double)ACC_SCALE)) / (float)N;
+    const int e = (k < 7) ? k : k + 1;      // words 9..11 are extras 10..12
+    W.extras[e] = m; if (W.out_extras) W.out_extras[e] = m;
   }
-  if (lane < 16) __hip_atomic_store(W.acc + lane, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct DrOut { int64_t* drc; uint32_t seed, dr_step; int64_t rand_buf, reset_key; uint32_t* sKey; };      // sKey: LDS [16][2] {corr key, fire}
@@ -892,23 +893,32 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     part[k] = v;
   }
-  // ---- means of the reward terms + success-rate windows (quadruped_pose_control.py:560,610,618-633; the co-train task keeps two more
-  // windows for its halves, joint_locomanipulation.py:795-859).  Every wavefront adds its 14 partial sums to int64 accumulators with
-  // relaxed device-scope atomics (returning, so that vmcnt(0) means "performed"), then takes a ticket; the last one to arrive reads
-  // the totals, publishes the extras and clears the accumulators for the next launch.  No fence, no second kernel.
-  long long dummy = 0;
+  // ---- means of the reward terms + success-rate windows.  Every wavefront adds its partial sums to a first-level row (row = block index
+  // mod acc_rows, so that 256 wavefronts do not serialise on one cache line) with ONE returning device-scope atomic per word; the word
+  // counts its arrivals, so the lane whose add completes a row's word knows it holds the row's total, adds that to the launch's word
+  // (row 0) the same way, and the lane that completes that one publishes the extras entry: two dependent round trips on the critical
+  // path, no ticket, no read-back, and every word is left zero for the next launch.  Integer sums: the totals do not depend on the order.
+  long long acc_old = 0, acc_add = 0;
+  long long* acc_row = W.acc;
   {
-    const bool first_task = (int)blockIdx.x < W.split_block;
+    const bool first_task = lm_block() < W.split_block;
     float mine = 0.f, tot0[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) { tot0[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part[k]))); mine = (lane == k) ? tot0[k] : mine; }   // lane 0 holds the sums
-    mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
-    mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
-    // 256 wavefronts adding to the same 14 addresses serialise 3600 read-modify-writes on one cache line (3.5 us of a 39 us step):
-    // the adds are spread over LM_ACC_COPIES accumulator rows (row = block index mod copies), which the last wavefront sums.  The
-    // per-step rows of the persistent rollout kernel (DEFER) are single rows: its blocks drift apart in time.
-    long long* row = DEFER ? W.acc : W.acc + 16 + (size_t)(blockIdx.x & (LM_ACC_COPIES - 1)) * 16;
-    if (lane < 14) dummy = __hip_atomic_fetch_add(row + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (DEFER) {      // per-step rows of the persistent rollout kernel: 14 plain fixed-point sums, read by k_rollout_finalize
+      mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
+      mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
+      if (lane < 14) acc_old = __hip_atomic_fetch_add(acc_row + lane, (long long)llrintf(mine * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const long long win = ((long long)llrintf(tot0[7]) << ACC_WIN_BITS) + (long long)llrintf(tot0[8]);      // (goal resets | resets) of these 16 envs
+      long long c = (long long)llrintf(mine * ACC_SCALE);
+      c = (lane == 7) ? win : c;
+      c = (lane == 8) ? (first_task ? win : 0LL) : c;
+      c = (lane == 12) ? (first_task ? 0LL : win) : c;
+      acc_add = c * (1LL << ACC_CNT_BITS) + 1LL;
+      acc_row = W.acc + 16 + (size_t)((int)blockIdx.x & (W.acc_rows - 1)) * 16;
+      if (lane < 13) acc_old = __hip_atomic_fetch_add(acc_row + lane, acc_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   const float clip = P->clip_obs;
   int nenv = min(ENVS_PER_WAVE, N - env0);
@@ -958,14 +968,20 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
   }
   if (!DEFER) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wavefront's atomics (and its stores) have been performed
-    asm volatile("" :: "v"(dummy));
-    int ticket = 0;
-    if (lane == 0) ticket = (int)__hip_atomic_fetch_add(W.acc + 15, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __shfl(ticket, 0);
-    if (ticket == (int)gridDim.x - 1) finalize_extras(P, W, N, lane, true);
+    const int rows = W.acc_rows, r = (int)blockIdx.x & (rows - 1);
+    const int in_row = ((int)gridDim.x - 1 - r) / rows + 1;      // wavefronts of this launch that add to row r
+    if (lane < 13 && (int)(acc_old & ACC_CNT_MASK) == in_row - 1) {
+      const long long t1 = (acc_old + acc_add) >> ACC_CNT_BITS;      // the row's total of word `lane`
+      __hip_atomic_store(acc_row + lane, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long add2 = t1 * (1LL << ACC_CNT_BITS) + 1LL;
+      const long long old2 = __hip_atomic_fetch_add(W.acc + lane, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(old2 & ACC_CNT_MASK) == min(rows, (int)gridDim.x) - 1) {
+        __hip_atomic_store(W.acc + lane, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish_extra(P, W, N, lane, (old2 + add2) >> ACC_CNT_BITS);
+      }
+    }
   } else {
-    asm volatile("" :: "v"(dummy));
+    asm volatile("" :: "v"(acc_old));
   }
 }
 
@@ -1004,7 +1020,7 @@ template <int MODE, int VAR, int DR, int DEFER = 0>
 LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float* sTab, float* sObs, float* sSt, float4* sStash) {
   TableRegs TR; table_fetch(A.table, threadIdx.x, TR);
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
-  const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
+  const int env0 = lm_block() * ENVS_PER_WAVE, envr = env0 + envl, N = A.N;
   const bool active = envr < N; const int env = active ? envr : (N - 1);
   const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE;
   const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
@@ -1214,7 +1230,7 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
-  const int env0 = blockIdx.x * ENVS_PER_WAVE;
+  const int env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash); }
   else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash); }
@@ -1227,7 +1243,7 @@ __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
-  const int env0 = blockIdx.x * ENVS_PER_WAVE;
+  const int env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash); }
   else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash); }
@@ -1264,7 +1280,7 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
   __shared__ float4 sStash[STASH_SLOTS * 64];
   __shared__ PolicySmem<NOBS, POLICY> PS;
-  const int t = threadIdx.x, env0 = blockIdx.x * ENVS_PER_WAVE;
+  const int t = threadIdx.x, env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
   for (int k = 0; k <= R.T; k++) {
     // The loop body must be compiled like a stand-alone kernel: without these opaque copies the compiler hoists every loop-invariant
@@ -1296,7 +1312,7 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
 }
 
 // extras and success windows of the T steps of a persistent rollout, in step order: the accumulator rows are fetched (and cleared) 64 steps
-// at a time, the window counters live in registers across the steps; same arithmetic as finalize_extras
+// at a time, the window counters live in registers across the steps; same arithmetic as publish_extra
 __global__ void __launch_bounds__(64) k_rollout_finalize(const lm_params* params, OutPtrs W, int N, long long* acc_steps, float* extras, int T) {
   __shared__ long long sAcc[64 * 16];
   __shared__ int sCnt[64 * 4];          // per step: goal resets, resets (all envs), goal resets, resets (first task)
@@ -1319,7 +1335,7 @@ __global__ void __launch_bounds__(64) k_rollout_finalize(const lm_params* params
       for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < nk * 16) { sAcc[i] = v[j]; __hip_atomic_store(acc_steps + 16 * (size_t)k0 + i, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
-    // the means of a step do not depend on the other steps: one lane per step (same arithmetic as finalize_extras)
+    // the means of a step do not depend on the other steps: one lane per step (same arithmetic as publish_extra)
     if (lane < nk) {
       const bool last = (k0 + lane == T - 1);
       float* ex = extras ? extras + (size_t)(k0 + lane) * LM_NUM_EXTRAS : nullptr;
@@ -1363,8 +1379,8 @@ __global__ void __launch_bounds__(64) k_reset_all(int64_t* cnt, int N) {
 // ---- test / tooling kernels ---------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_apply_resets(StepArgs A) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
-  const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; if (envr >= N) return; const int env = envr;
-  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  const int envr = lm_block() * ENVS_PER_WAVE + envl, N = A.N; if (envr >= N) return; const int env = envr;
+  const lm_params* P = A.params + ((lm_block() * ENVS_PER_WAVE >= A.split) ? 1 : 0);
   const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   float* st = A.state; int64_t* cnt = A.cnt;
   if (cnt[3 * (size_t)N + env] == 0) return;
@@ -1426,7 +1442,7 @@ template <int MODE, int VAR>
 LM_DEV void substeps_body(const StepArgs& A, const lm_params* P, const float* sTab, const float* targets, int n, float4* sStash) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
   Stash St; St.base = sStash; St.lane = lane;
-  const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
+  const int envr = lm_block() * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
   const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   FreeBody F; float q[3], qd[3], tgt[3];
   load_phys<MODE>(A.state, N, env, limb, F, q, qd);
@@ -1442,7 +1458,7 @@ __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* target
   __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   __shared__ float4 sStash[STASH_SLOTS * 64];
   load_table(A.table, sTab, threadIdx.x);
-  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  const lm_params* P = A.params + ((lm_block() * ENVS_PER_WAVE >= A.split) ? 1 : 0);
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) substeps_body<0, 0>(A, P, sTab, targets, n, sStash); else substeps_body<1, 0>(A, P, sTab, targets, n, sStash); }
   else { if (P->mode == LM_MODE_LOCO) substeps_body<0, 1>(A, P, sTab, targets, n, sStash); else substeps_body<1, 1>(A, P, sTab, targets, n, sStash); }
 }
@@ -1450,9 +1466,9 @@ __global__ void __launch_bounds__(64) k_substeps(StepArgs A, const float* target
 __global__ void __launch_bounds__(64) k_fk(StepArgs A, float* tips, float* knees) {
   __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
   load_table(A.table, sTab, threadIdx.x);
-  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  const lm_params* P = A.params + ((lm_block() * ENVS_PER_WAVE >= A.split) ? 1 : 0);
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
-  const int env = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; if (env >= N) return;
+  const int env = lm_block() * ENVS_PER_WAVE + envl, N = A.N; if (env >= N) return;
   const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE;
   FreeBody F; float q[3], qd[3];
   M3 Rb; V3 pb;
@@ -1473,7 +1489,7 @@ __global__ void __launch_bounds__(64) k_debug_dyn(StepArgs A, float* Mout, float
   load_table(A.table, sTab, threadIdx.x);
   const lm_params* P = A.params;
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
-  const int envr = blockIdx.x * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
+  const int envr = lm_block() * ENVS_PER_WAVE + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
   const float* tl = sTab + HUB_FLOATS + limb * LIMB_STRIDE; const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   FreeBody F; float q[3], qd[3];
   load_phys<0>(A.state, N, env, limb, F, q, qd);
@@ -1502,7 +1518,7 @@ __global__ void __launch_bounds__(64) k_debug_dyn(StepArgs A, float* Mout, float
 template <int MODE>
 LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* rb_all, float* sObs, float* sSt) {
   const int lane = threadIdx.x, limb = lane & 3, envl = lane >> 2;
-  const int env0 = blockIdx.x * ENVS_PER_WAVE, envr = env0 + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
+  const int env0 = lm_block() * ENVS_PER_WAVE, envr = env0 + envl, N = A.N; const bool active = envr < N; const int env = active ? envr : N - 1;
   const int jj[3] = {limb, 4 + 2 * limb, 5 + 2 * limb};
   float* st = A.state; int64_t* cnt = A.cnt;
   const float* rb = rb_all + (size_t)env * 99;
@@ -1539,7 +1555,7 @@ LM_DEV void task_only_body(const StepArgs& A, const lm_params* P, const float* r
 __global__ void __launch_bounds__(64) k_task_eval(StepArgs A, const float* readback) {
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
   __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
-  const lm_params* P = A.params + ((blockIdx.x * ENVS_PER_WAVE >= A.split) ? 1 : 0);
+  const lm_params* P = A.params + ((lm_block() * ENVS_PER_WAVE >= A.split) ? 1 : 0);
   if (P->mode == LM_MODE_LOCO) task_only_body<0>(A, P, readback, sObs, sSt); else task_only_body<1>(A, P, readback, sObs, sSt);
 }
 
@@ -1581,6 +1597,7 @@ const char* lm_version(void) { return "lm_engine 0.1 (gfx950)"; }
 int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks, int split_env, uint32_t seed) {
   if (!out || !table || !params) return fail(LM_EINVAL, "lm_create: null argument");
   if (n_envs <= 0) return fail(LM_EINVAL, "lm_create: n_envs must be positive");
+  if (n_envs >= (1 << (ACC_WIN_BITS - 1))) return fail(LM_EINVAL, "lm_create: n_envs must be below 2^25 per engine (width of the reset counts in the extras reduction)");
   if (n_tasks != 1 && n_tasks != 2) return fail(LM_EINVAL, "lm_create: n_tasks must be 1 or 2");
   if (n_tasks == 2 && (split_env <= 0 || split_env >= n_envs || (split_env % ENVS_PER_WAVE) != 0))
     return fail(LM_EINVAL, "lm_create: split_env must be a multiple of 16 inside (0, n_envs)");
@@ -1629,7 +1646,9 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   ALLOC(h->d_rew, N * sizeof(float));
   ALLOC(h->d_extras, 16 * sizeof(float));
   ALLOC(h->d_terms, LM_TERM_ROWS * N * sizeof(float));
-  ALLOC(h->d_acc, (16 + (size_t)LM_ACC_COPIES * 16) * sizeof(long long));      // row 0: ticket (+ totals of the legacy path); rows 1..: spread accumulators
+  h->acc_rows = LM_ACC_COPIES;      // a counted accumulator word takes at most 4095 arrivals (write_outputs)
+  while (((N + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE + h->acc_rows - 1) / h->acc_rows > (int)ACC_CNT_MASK) h->acc_rows *= 2;
+  ALLOC(h->d_acc, (16 + (size_t)h->acc_rows * 16) * sizeof(long long));      // row 0: totals of a launch; rows 1..: first-level rows
   ALLOC(h->d_stats, 64);
 #undef ALLOC
   float itab[LM_ITAB_FLOATS]; permute_table(table, itab);      // public packed layout -> the device's chain-interleaved layout
@@ -1670,7 +1689,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   StepArgs A;
   A.params = h->d_params; A.table = h->d_table; A.state = h->d_state; A.cnt = h->d_cnt; A.actions = actions; A.goal_rand = goal_rand;
   A.W.obs_buf = h->d_obs; A.W.states_buf = h->d_states; A.W.rew_buf = h->d_rew; A.W.terms = h->d_terms; A.W.acc = h->d_acc;
-  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE;
+  A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE; A.W.acc_rows = h->acc_rows;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
   A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
   return A;
