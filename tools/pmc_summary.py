@@ -21,7 +21,9 @@ if __name__ == "__main__":
             if k in ("FETCH_SIZE", "WRITE_SIZE"): pw[k + "_KB"] = round(v, 2)
             elif k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY"): pw[k + "_quad"] = round(v, 1)
             else: pw[k] = round(v, 1)
-        fetch = per_wave.get("FETCH_SIZE", 0.0) * 1024 * waves; write = per_wave.get("WRITE_SIZE", 0.0) * 1024 * waves
+        # FETCH_SIZE reads half of the bytes on gfx950 (MI355X_MICROARCH.md, HBM section) - for one dword per lane as well as for 16 B per lane
+        # (profiles/r02_fetch_calib.json, tools/microbench/fetch_calib.hip); WRITE_SIZE reads the bytes exactly
+        fetch = per_wave.get("FETCH_SIZE", 0.0) * 2048 * waves; write = per_wave.get("WRITE_SIZE", 0.0) * 1024 * waves
         # fp32 VALU instruction counters: a packed instruction (v_pk_fma_f32 ...) does two lanes' worth of arithmetic per lane but is ONE
         # instruction, so this is a LOWER bound of the flops since round 2 (the step kernel issues about a third of its fp32 work packed)
         flop = (per_wave.get("SQ_INSTS_VALU_ADD_F32", 0) + per_wave.get("SQ_INSTS_VALU_MUL_F32", 0) + per_wave.get("SQ_INSTS_VALU_TRANS_F32", 0)
@@ -32,7 +34,7 @@ if __name__ == "__main__":
                       f"4096 envs = {waves} wavefronts per launch (tools/profile_round.sh)",
             "per_wave": pw,
             "per_launch": {"fetch_bytes": fetch, "write_bytes": write, "hbm_traffic_bytes": fetch + write,
-                           "note": "FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950 (the guide's x2 correction applies to 16 B/lane streams only); "
+                           "note": "fetch_bytes = FETCH_SIZE x 2 (the gfx950 correction, checked for 4 B/lane loads in profiles/r02_fetch_calib.json); "
                                    "writes include the unclipped obs_buf/states_buf copies the API exposes (+628 B/env) and the per-env reward terms (+44 B/env)"},
             "wave": {"valu_instructions": round(vi, 1), "wave_quad_cycles": round(wc, 1), "wait_quad_cycles": round(wa, 1),
                      "valu_issue_fraction": round(vi / wc, 4) if wc else None, "wait_fraction": round(wa / wc, 4) if wc else None,
