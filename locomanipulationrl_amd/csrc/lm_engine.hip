@@ -457,6 +457,22 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
   a = sv(v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y)); b = sv(v3(t1.z, t1.w, t2.x), v3(t2.y, t2.z, t2.w)); c = sv(v3(t3.x, t3.y, t3.z), v3(t3.w, t4.x, t4.y));
 }
 
+// Diagnostic build only (-DLM_STAMPS, tools/stamp_profile.sh): LM_STAMP(k) adds the shader cycles since the previous stamp to bucket k of
+// a per-workgroup LDS array that k_step copies to lm_stamp_out.  No stamp exists in the product build.
+#ifdef LM_STAMPS
+__device__ unsigned long long lm_stamp_out[1024 * 16];
+__shared__ unsigned long long lm_stamp_lds[16];
+#if LM_STAMPS == 2      // only the wavefront's lifetime (two clock reads around the whole body): what the product code takes inside the kernel
+#define LM_STAMP(k) do { } while (0)
+#else
+#define LM_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (threadIdx.x == 0) { lm_stamp_lds[k] += t_ - lm_stamp_lds[15]; lm_stamp_lds[15] = t_; } } while (0)
+#endif
+#else
+#define LM_STAMP(k) do { } while (0)
+#endif
+
 // One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
 // robot base is fixed at (Rb, pb).
 template <int MODE, int VAR, int DR>
@@ -473,6 +489,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     SV avp0 = sv(v3(0, 0, 0), DR ? mulT(Rb, -X.g) : P->gravity * row2(Rb));      // fictitious acceleration = -gravity
     LimbKin K; limb_kinematics(tl, q, qd, K);
     LimbDyn D; limb_dynamics(tl, K, qd, v0, avp0, D);
+    LM_STAMP(1);
     if (MODE == 0) {
       // the hub body itself rides on limb 0's contribution to the quad reductions
       const float m0 = (limb == 0) ? 1.f : 0.f;
@@ -545,6 +562,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     }
   }
 
+  LM_STAMP(2);
   // effort mode (RobotOmni.take_action, robot.py:455-459): tgt IS the joint torque, gains off = the constant-torque branch from the start
   const bool effort = (VAR == 0) && P->drive_mode == LM_DRIVE_EFFORT;
   bool sat[3] = {effort, effort, effort}; float tsat[3] = {effort ? tgt[0] : 0.f, effort ? tgt[1] : 0.f, effort ? tgt[2] : 0.f};
@@ -659,7 +677,9 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       vf[2] = b.y + (Jq[2][0] * qdf[0] + Jq[2][1] * qdf[1] + Jq[2][2] * qdf[2]);
     }
     float lam[3], w[6];
+    LM_STAMP(3);
     pgs_solve(P->pgs_iters, limb, P->mu, bn, vf, Wl, T, X, lam, w);
+    LM_STAMP(4);
     // apply impulses
     un = sv(v3(v0f[0] + w[0], v0f[1] + w[1], v0f[2] + w[2]), v3(v0f[3] + w[3], v0f[4] + w[4], v0f[5] + w[5]));
 #pragma unroll
@@ -692,6 +712,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   }
   F.u = un;
   integrate_free(F, Rf, dt);
+  LM_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,6 +732,17 @@ template <int MODE, int VAR>
 LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const TaskIn& I, TaskState& S, TaskOut& O,
                       float* sObs, float* sSt) {
   S.progress += 1;
+  // Every parameter the task layer reads, fetched in ONE batch of loads: read where they are used (inside || chains and after branches) each
+  // one was a load the compiler may not hoist, i.e. an exposed cache round trip for the lone wavefront - twenty of them in a row.
+  struct { float s_pos, s_lin, s_ang, s_q, s_qd, quat_scale, rot_eps, trans_scale, acc_scale, rate_scale, bonus, limit_pen, fall_pen, succ_thresh, h_base, h_corner, h_knee;
+           float d23_pen[2], d23_rst[2], d1_pen[2], d1_rst[2], corner[3]; int max_consec, max_episode; } C;
+  C.s_pos = P->s_pos; C.s_lin = P->s_lin; C.s_ang = P->s_ang; C.s_q = P->s_q; C.s_qd = P->s_qd; C.quat_scale = P->quat_scale; C.rot_eps = P->rot_eps;
+  C.trans_scale = P->trans_scale; C.acc_scale = P->acc_scale; C.rate_scale = P->rate_scale; C.bonus = P->bonus; C.limit_pen = P->limit_pen;
+  C.fall_pen = P->fall_pen; C.succ_thresh = P->succ_thresh; C.h_base = P->h_base; C.h_corner = P->h_corner; C.h_knee = P->h_knee;
+  C.d23_pen[0] = P->d23_pen[0]; C.d23_pen[1] = P->d23_pen[1]; C.d23_rst[0] = P->d23_rst[0]; C.d23_rst[1] = P->d23_rst[1];
+  C.d1_pen[0] = P->d1_pen[limb][0]; C.d1_pen[1] = P->d1_pen[limb][1]; C.d1_rst[0] = P->d1_rst[limb][0]; C.d1_rst[1] = P->d1_rst[limb][1];
+  C.corner[0] = P->corner[limb][0]; C.corner[1] = P->corner[limb][1]; C.corner[2] = P->corner[limb][2];
+  C.max_consec = P->max_consec; C.max_episode = P->max_episode;
   V3 opos, olin, oang; Q4 oq; M3 Rr; V3 pr;
   if (MODE == 0) {
     Rr = quat_to_mat(I.fq.w, I.fq.x, I.fq.y, I.fq.z); pr = I.fp;
@@ -733,15 +765,15 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   const int j1 = limb, j2 = 4 + 2 * limb, j3 = 5 + 2 * limb;
   float* ob = sObs + envl * NO; float* st = sSt + envl * 93;
   if (limb == 0) {
-    ob[0] = P->s_pos * opos.x; ob[1] = P->s_pos * opos.y; ob[2] = P->s_pos * opos.z;
+    ob[0] = C.s_pos * opos.x; ob[1] = C.s_pos * opos.y; ob[2] = C.s_pos * opos.z;
     ob[3] = up.x; ob[4] = up.y; ob[5] = up.z;
     ob[6] = qf.w; ob[7] = qf.x; ob[8] = qf.y; ob[9] = qf.z;
-    ob[10] = P->s_lin * olin.x; ob[11] = P->s_lin * olin.y; ob[12] = P->s_lin * olin.z;
-    ob[13] = P->s_ang * oang.x; ob[14] = P->s_ang * oang.y; ob[15] = P->s_ang * oang.z;
-    st[0] = P->s_pos * opos.x; st[1] = P->s_pos * opos.y; st[2] = P->s_pos * opos.z;
-    st[3] = P->s_lin * olin.x; st[4] = P->s_lin * olin.y; st[5] = P->s_lin * olin.z;
+    ob[10] = C.s_lin * olin.x; ob[11] = C.s_lin * olin.y; ob[12] = C.s_lin * olin.z;
+    ob[13] = C.s_ang * oang.x; ob[14] = C.s_ang * oang.y; ob[15] = C.s_ang * oang.z;
+    st[0] = C.s_pos * opos.x; st[1] = C.s_pos * opos.y; st[2] = C.s_pos * opos.z;
+    st[3] = C.s_lin * olin.x; st[4] = C.s_lin * olin.y; st[5] = C.s_lin * olin.z;
     st[6] = oq.w; st[7] = oq.x; st[8] = oq.y; st[9] = oq.z;
-    st[10] = P->s_ang * oang.x; st[11] = P->s_ang * oang.y; st[12] = P->s_ang * oang.z;
+    st[10] = C.s_ang * oang.x; st[11] = C.s_ang * oang.y; st[12] = C.s_ang * oang.z;
     st[37] = S.goal.w; st[38] = S.goal.x; st[39] = S.goal.y; st[40] = S.goal.z;
     st[41] = qf.w; st[42] = qf.x; st[43] = qf.y; st[44] = qf.z;
   }
@@ -749,8 +781,8 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     int j = jj[a];
-    ob[16 + j] = P->s_q * I.q[a]; ob[28 + j] = P->s_qd * I.qd[a]; ob[40 + j] = var2 ? 0.3f * I.tgtq[a] : I.act[a]; ob[52 + j] = var2 ? 0.3f * S.ltgt[a] : S.lact[a];      // position-control tasks: targets replace the actions (…position_control.py:438-453)
-    st[13 + j] = P->s_q * I.q[a]; st[25 + j] = P->s_qd * I.qd[a]; st[69 + j] = I.act[a]; st[81 + j] = S.lact[a];
+    ob[16 + j] = C.s_q * I.q[a]; ob[28 + j] = C.s_qd * I.qd[a]; ob[40 + j] = var2 ? 0.3f * I.tgtq[a] : I.act[a]; ob[52 + j] = var2 ? 0.3f * S.ltgt[a] : S.lact[a];      // position-control tasks: targets replace the actions (…position_control.py:438-453)
+    st[13 + j] = C.s_q * I.q[a]; st[25 + j] = C.s_qd * I.qd[a]; st[69 + j] = I.act[a]; st[81 + j] = S.lact[a];
     if (var1) { ob[64 + j] = 0.3f * I.tgtq[a]; ob[76 + j] = 0.3f * S.ltgt[a]; }      // :432-455
   }
   st[45 + 3 * limb] = btip.x; st[46 + 3 * limb] = btip.y; st[47 + 3 * limb] = btip.z;
@@ -759,11 +791,11 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   // ---- calculate_metrics
   float vn = fminf(sqrtf(qd_.x * qd_.x + qd_.y * qd_.y + qd_.z * qd_.z), 1.0f);
   float rot_dist = 2.0f * asinf(vn);
-  float rot_rew = P->quat_scale / (fabsf(rot_dist) + P->rot_eps);
-  float trans = sqrtf(opos.x * opos.x + opos.y * opos.y) * P->trans_scale;
-  float accp = quad_sum(fabsf(I.acc[0]) * P->acc_scale + fabsf(I.acc[1]) * P->acc_scale + fabsf(I.acc[2]) * P->acc_scale);
+  float rot_rew = C.quat_scale / (fabsf(rot_dist) + C.rot_eps);
+  float trans = sqrtf(opos.x * opos.x + opos.y * opos.y) * C.trans_scale;
+  float accp = quad_sum(fabsf(I.acc[0]) * C.acc_scale + fabsf(I.acc[1]) * C.acc_scale + fabsf(I.acc[2]) * C.acc_scale);
   float rate = quad_sum(var1 ? (fabsf(I.act[0]) + fabsf(I.act[1]) + fabsf(I.act[2]))
-                             : (fabsf(S.lact[0] - I.act[0]) + fabsf(S.lact[1] - I.act[1]) + fabsf(S.lact[2] - I.act[2]))) * P->rate_scale;
+                             : (fabsf(S.lact[0] - I.act[0]) + fabsf(S.lact[1] - I.act[1]) + fabsf(S.lact[2] - I.act[2]))) * C.rate_scale;
   float powp = 0.f, terr = 0.f, rdec = 0.f;
   if (var1) {      // mechanical power, position-target error, rot-dist-decreasing terms (:530-545)
     powp = quad_sum(fabsf(I.torque[0] * I.qd[0]) + fabsf(I.torque[1] * I.qd[1]) + fabsf(I.torque[2] * I.qd[2])) * P->power_scale;
@@ -771,14 +803,14 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
     rdec = ((rot_dist > P->rot_dec_thresh) ? 1.f : 0.f) * (S.lrd - rot_dist) * P->rot_dec_scale;
     S.lrd = rot_dist;
   }
-  int cgr = (S.consec > P->max_consec) ? 1 : 0;
-  float bonus = P->bonus * (float)cgr;
-  int succ = (fabsf(rot_dist) <= P->succ_thresh) ? 1 : 0;
+  int cgr = (S.consec > C.max_consec) ? 1 : 0;
+  float bonus = C.bonus * (float)cgr;
+  int succ = (fabsf(rot_dist) <= C.succ_thresh) ? 1 : 0;
   float dd = fabsf(I.q[2] - I.q[1]);
-  int brk = ((dd < P->d23_pen[0]) || (dd > P->d23_pen[1])) + ((I.q[0] < P->d1_pen[limb][0]) || (I.q[0] > P->d1_pen[limb][1]));
-  int rst = ((dd < P->d23_rst[0]) || (dd > P->d23_rst[1])) + ((I.q[0] < P->d1_rst[limb][0]) || (I.q[0] > P->d1_rst[limb][1]));
+  int brk = (int)((dd < C.d23_pen[0]) | (dd > C.d23_pen[1])) + (int)((I.q[0] < C.d1_pen[0]) | (I.q[0] > C.d1_pen[1]));
+  int rst = (int)((dd < C.d23_rst[0]) | (dd > C.d23_rst[1])) + (int)((I.q[0] < C.d1_rst[0]) | (I.q[0] > C.d1_rst[1]));
   brk = quad_sum_i(brk); rst = quad_sum_i(rst);
-  float limp = (brk > 0) ? P->limit_pen : 0.f;
+  float limp = (brk > 0) ? C.limit_pen : 0.f;
   float total = rot_rew + trans + accp + rate + bonus + limp + powp + terr + rdec;
   S.greset = cgr;
   int both = (succ && S.succ) ? 1 : 0;
@@ -793,18 +825,18 @@ LM_DEV void task_eval(const lm_params* __restrict__ P, int limb, int envl, const
   M3 Rp; V3 pp;
   if (MODE == 0) { Rp.c0 = v3(1, 0, 0); Rp.c1 = v3(0, 1, 0); Rp.c2 = v3(0, 0, 1); pp = v3(0, 0, 0); }
   else { Rp = quat_to_mat(I.fq.w, I.fq.x, I.fq.y, I.fq.z); pp = I.fp; }
-  if (mulT(Rp, pr - pp).z <= P->h_base) reset = 1;
-  V3 cw = pr + mul(Rr, v3(P->corner[limb][0], P->corner[limb][1], P->corner[limb][2]));
-  int nlow = (mulT(Rp, cw - pp).z < P->h_corner) ? 1 : 0;
-  nlow += (mulT(Rp, I.knee2 - pp).z - P->h_knee <= 0.f) ? 1 : 0;
-  nlow += (mulT(Rp, I.knee3 - pp).z - P->h_knee <= 0.f) ? 1 : 0;
+  if (mulT(Rp, pr - pp).z <= C.h_base) reset = 1;
+  V3 cw = pr + mul(Rr, v3(C.corner[0], C.corner[1], C.corner[2]));
+  int nlow = (mulT(Rp, cw - pp).z < C.h_corner) ? 1 : 0;
+  nlow += (mulT(Rp, I.knee2 - pp).z - C.h_knee <= 0.f) ? 1 : 0;
+  nlow += (mulT(Rp, I.knee3 - pp).z - C.h_knee <= 0.f) ? 1 : 0;
   nlow = quad_sum_i(nlow);
   if (nlow > 0) reset = 1;
   if (rst > 0) reset = 1;
-  float fallp = P->fall_pen * (float)reset;
+  float fallp = C.fall_pen * (float)reset;
   total += fallp;
   if (cgr == 1) reset = 1;
-  if (S.progress >= P->max_episode - 1) reset = 1;
+  if (S.progress >= C.max_episode - 1) reset = 1;
   S.reset = reset;
   O.rew = total;
   O.terms[0] = rot_rew; O.terms[1] = trans; O.terms[2] = accp; O.terms[3] = rate; O.terms[4] = bonus; O.terms[5] = limp; O.terms[6] = fallp; O.terms[7] = (float)cgr;
@@ -967,6 +999,7 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
 #pragma unroll
     for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
   }
+  LM_STAMP(9);      // partial sums, atomics issued, output stores issued
   if (!DEFER) {
     const int rows = W.acc_rows, r = (int)blockIdx.x & (rows - 1);
     const int in_row = ((int)gridDim.x - 1 - r) / rows + 1;      // wavefronts of this launch that add to row r
@@ -1097,6 +1130,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   M3 Rfix; V3 pfix = v3(P->fixed_base_pos[0], P->fixed_base_pos[1], P->fixed_base_pos[2]);
   Rfix = quat_to_mat(P->fixed_base_quat[0], P->fixed_base_quat[1], P->fixed_base_quat[2], P->fixed_base_quat[3]);
   table_commit(TR, sTab, lane);
+  LM_STAMP(0);
   float tau_acc[3] = {0.f, 0.f, 0.f}, tgtq[3] = {0.f, 0.f, 0.f}, qda[3] = {0.f, 0.f, 0.f}; bool qda_set = false;
   constexpr bool pd = (VAR >= 1);
   const int nsub = (A.nsub < 0) ? P->substeps : A.nsub;
@@ -1182,6 +1216,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
       if (active && limb == 0) atomicAdd(reinterpret_cast<unsigned int*>(A.W.stats + 60), 1u);      // contained blow-ups since creation (LM_PTR_STATS)
     }
   }
+  LM_STAMP(6);      // task-state loads, reset scatter, blow-up guard
   // ---- read-back (robot.py:276-321)
   TaskIn I;
   M3 Rf = quat_to_mat(F.q.w, F.q.x, F.q.y, F.q.z);
@@ -1193,11 +1228,13 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
     M3 Rb = (MODE == 0) ? Rf : Rfix; V3 pb = (MODE == 0) ? F.p : pfix;
     I.tipw = pb + mul(Rb, x); I.knee2 = pb + mul(Rb, k2); I.knee3 = pb + mul(Rb, k3);
   }
+  const float acc_dt_inv = P->acc_dt_inv, ctrl_dt_inv = P->ctrl_dt_inv, torque_div = pd ? P->torque_div : 1.f;      // one batch of loads (see task_eval)
 #pragma unroll
-  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (pd && qda_set) ? (qd[a] - qda[a]) * P->acc_dt_inv : (qd[a] - lqd[a]) * P->ctrl_dt_inv; I.act[a] = act[a];
-    I.torque[a] = pd ? tau_acc[a] / P->torque_div : 0.f; I.tgtq[a] = tgtq[a]; }      // logged torque = sum over sub-steps / control_decimal (:307)
+  for (int a = 0; a < 3; a++) { I.q[a] = q[a]; I.qd[a] = qd[a]; I.acc[a] = (pd && qda_set) ? (qd[a] - qda[a]) * acc_dt_inv : (qd[a] - lqd[a]) * ctrl_dt_inv; I.act[a] = act[a];
+    I.torque[a] = pd ? tau_acc[a] / torque_div : 0.f; I.tgtq[a] = tgtq[a]; }      // logged torque = sum over sub-steps / control_decimal (:307)
   TaskOut O;
   task_eval<MODE, VAR>(P, limb, envl, I, S, O, sObs, sSt);
+  LM_STAMP(7);      // read-back kinematics + task layer
   if (blown) S.reset = 1;
   // ---- store state
   if (active) {
@@ -1222,7 +1259,9 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   }
   DrOut DO; DO.drc = A.drc; DO.seed = A.seed; DO.dr_step = dr_step; DO.rand_buf = dr_rand_buf; DO.reset_key = dr_reset_key;
   DO.sKey = reinterpret_cast<uint32_t*>(sStash);      // the stash is dead after the last sub-step
+  LM_STAMP(8);      // state stores issued
   write_outputs<DR, DEFER>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
+  LM_STAMP(10);     // the reduction's round trips
 }
 
 __global__ void __launch_bounds__(64) k_step(StepArgs A) {
@@ -1232,9 +1271,21 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   __shared__ float4 sStash[STASH_SLOTS * 64];
   const int env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+#ifdef LM_STAMPS
+  if (threadIdx.x < 16) lm_stamp_lds[threadIdx.x] = 0;
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if (threadIdx.x == 0) lm_stamp_lds[15] = t0_; }
+  LM_STAMP(11); LM_STAMP(12);      // two stamps back to back: bucket 12 = the cost of a stamp
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
+#endif
   if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash); }
   else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash); }
   else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(A, P, sTab, sObs, sSt, sStash); }
+#ifdef LM_STAMPS
+  { const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime(), mt1_ = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { lm_stamp_lds[13] = mt1_ - mt0_; lm_stamp_lds[14] = rt1_ - rt0_; } }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (threadIdx.x < 16 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 16 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
+#endif
 }
 
 // the same step with domain randomisation (a separate kernel so that the un-randomised k_step above is untouched)
@@ -1694,6 +1745,10 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
   return A;
 }
+
+#ifdef LM_STAMPS
+extern "C" int lm_debug_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(lm_stamp_out), sizeof(lm_stamp_out)) == hipSuccess ? 0 : -1; }
+#endif
 
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states, float* out_rew,
             int64_t* out_resets, float* out_extras, void* stream) {

@@ -19,3 +19,6 @@ print("post_physics (no sub-steps) %.2f us" % timeit(lambda: eng.post_physics(a,
 print("post_physics no outputs     %.2f us" % timeit(lambda: eng.post_physics(a)))
 print("step                        %.2f us" % timeit(lambda: eng.step(a, None, *o)))
 print("fk kernel                   %.2f us" % timeit(lambda: eng.forward_kinematics()))
+# how much of the step period is the volume of output stores (the end-of-kernel write-back of the XCDs' L2s)?
+print("step, no returned copies    %.2f us" % timeit(lambda: eng.step(a)))
+print("step, returned obs only     %.2f us" % timeit(lambda: eng.step(a, None, o[0])))

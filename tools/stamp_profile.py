@@ -1,0 +1,47 @@
+"""Where a k_step wavefront spends its shader cycles: per-phase s_memtime stamps of a DIAGNOSTIC build (-DLM_STAMPS).
+    python tools/stamp_profile.py --build      (here: hipcc, writes tools/diag/liblm_engine_stamps.so, which travels with gpurun)
+    python tools/stamp_profile.py              (GPU box: loads that library through LM_ENGINE_SO, prints one JSON document)
+The product library contains no stamp; the stamped build is ~10 % slower (each stamp drains the LDS queue)."""
+import ctypes as C, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tools", "diag", "liblm_engine_stamps.so")
+NAMES = {0: "entry: physical-state loads, table to LDS", 1: "sub-steps: limb kinematics + dynamics", 2: "sub-steps: hub term, contact geometry, stash writes",
+         3: "sub-steps: pass linear algebra (stash reads, K, hub sums, Cholesky, 4 solves, Delassus blocks)", 4: "sub-steps: PGS sweeps",
+         5: "sub-steps: impulses, saturation test, integration", 6: "task-state loads, reset scatter, blow-up guard", 7: "read-back kinematics + task layer",
+         8: "state stores", 9: "partial sums, atomics + output stores issued", 10: "reduction round trips (this wavefront's)", 12: "(cost of one stamp)"}
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    csrc = os.path.join(ROOT, "locomanipulationrl_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+                           "-fPIC", "-shared", "-DLM_STAMPS", os.path.join(csrc, "lm_engine.hip"), os.path.join(csrc, "lm_policy.hip"), "-o", SO])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+                           "-fPIC", "-shared", "-DLM_STAMPS=2", os.path.join(csrc, "lm_engine.hip"), os.path.join(csrc, "lm_policy.hip"), "-o", SO.replace("stamps.so", "lifetime.so")])
+    print("built", SO); sys.exit(0)
+if "--lifetime" in sys.argv: SO = SO.replace("stamps.so", "lifetime.so")
+os.environ["LM_ENGINE_SO"] = SO
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from locomanipulationrl_amd.engine_config import loco_params, mani_params
+from locomanipulationrl_amd.lib import Engine, load_library
+from locomanipulationrl_amd.model.robot_model import load_model
+lib = load_library()
+out = {}
+for name, params, N in (("loco_4096", loco_params(), 4096), ("mani_4096", mani_params(), 4096), ("loco_16384", loco_params(), 16384)):
+    eng = Engine(load_model("quadruped_robot_v2"), [params], N, seed=42)
+    g = torch.Generator(device="cuda"); g.manual_seed(42)
+    acts = [torch.rand(N, 12, device="cuda", generator=g) * 2 - 1 for _ in range(50)]
+    for i in range(300): eng.step(acts[i % 50])
+    torch.cuda.synchronize(); import time; t0 = time.perf_counter()
+    for i in range(1000): eng.step(acts[i % 50])
+    torch.cuda.synchronize(); period_us = (time.perf_counter() - t0) / 1000 * 1e6
+    buf = np.zeros(1024 * 16, dtype=np.uint64)
+    assert lib.lm_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
+    b = buf.reshape(1024, 16)[: min(1024, N // 16)].astype(np.float64)
+    stamp = float(np.median(b[:, 12])); nst = {0: 1, 1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 1, 7: 1, 8: 1, 9: 1, 10: 1}
+    med = {k: float(np.median(b[:, k])) for k in nst}
+    tot = sum(med.values())
+    out[name] = {"step_period_us_this_build": round(period_us, 2), "stamp_cost_cycles": stamp, "wave_cycles_stamped_build": tot, "wave_memtime_ticks": float(np.median(b[:, 13])),
+                 "wave_realtime_us": float(np.median(b[:, 14])) / 100.0, "memtime_ticks_per_us": float(np.median(b[:, 13] / np.maximum(b[:, 14], 1.0))) * 100.0,
+                 "phases": {NAMES[k]: {"cycles": round(med[k]), "minus_stamps": round(med[k] - nst[k] * stamp), "share": round(med[k] / max(tot, 1.0), 4)} for k in nst}}
+    del eng
+print(json.dumps(out, indent=1))
