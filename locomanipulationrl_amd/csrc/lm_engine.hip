@@ -893,7 +893,7 @@ LM_DEV void publish_extra(const lm_params* __restrict__ P, const OutPtrs& W, int
 
 struct DrOut { int64_t* drc; uint32_t seed, dr_step; int64_t rand_buf, reset_key; uint32_t* sKey; };      // sKey: LDS [16][2] {corr key, fire}
 
-template <int DR, int DEFER = 0>      // DEFER 1: only accumulate; the extras of this step are published later (persistent rollout kernel)
+template <int DR, int DEFER = 0, int NOBS = 0>      // DEFER 1: only accumulate; the extras of this step are published later (persistent rollout kernel); NOBS 0: width from the parameters
 LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int N, int env0, int lane, int limb, int env, bool active,
                           const TaskState& S, const TaskOut& O, int64_t* cnt, int episode, float* sObs, float* sSt, const DrOut& DO) {
   if (DR) {
@@ -911,19 +911,15 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS staging writes landed (single wave per block)
   __builtin_amdgcn_wave_barrier();
-  // per-block partial sums (fixed order -> deterministic means)
-  float part[12];
-  bool cnts = active && (limb == 0);
+  // per-block partial sums in a fixed order (deterministic means).  Every lane of a quad holds its env's terms; lane 3 is the one that counts
+  float tot0[12];
+  {
+    const bool cnts = active && (limb == 3);
 #pragma unroll
-  for (int k = 0; k < 8; k++) part[k] = cnts ? O.terms[k] : 0.f;
-  part[8] = cnts ? (float)S.reset : 0.f;
+    for (int k = 0; k < 8; k++) tot0[k] = wave_sum_lane3(cnts ? O.terms[k] : 0.f);
+    tot0[8] = wave_sum_lane3(cnts ? (float)S.reset : 0.f);
 #pragma unroll
-  for (int k = 0; k < 3; k++) part[9 + k] = cnts ? O.terms[8 + k] : 0.f;
-#pragma unroll
-  for (int k = 0; k < 12; k++) {
-    float v = part[k];
-    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-    part[k] = v;
+    for (int k = 0; k < 3; k++) tot0[9 + k] = wave_sum_lane3(cnts ? O.terms[8 + k] : 0.f);
   }
   // ---- means of the reward terms + success-rate windows.  Every wavefront adds its partial sums to a first-level row (row = block index
   // mod acc_rows, so that 256 wavefronts do not serialise on one cache line) with ONE returning device-scope atomic per word; the word
@@ -934,9 +930,9 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   long long* acc_row = W.acc;
   {
     const bool first_task = lm_block() < W.split_block;
-    float mine = 0.f, tot0[12];
+    float mine = 0.f;
 #pragma unroll
-    for (int k = 0; k < 12; k++) { tot0[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part[k]))); mine = (lane == k) ? tot0[k] : mine; }   // lane 0 holds the sums
+    for (int k = 0; k < 12; k++) mine = (lane == k) ? tot0[k] : mine;
     if (DEFER) {      // per-step rows of the persistent rollout kernel: 14 plain fixed-point sums, read by k_rollout_finalize
       mine = (lane == 12) ? (first_task ? tot0[7] : 0.f) : mine;
       mine = (lane == 13) ? (first_task ? tot0[8] : 0.f) : mine;
@@ -954,7 +950,25 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
   }
   const float clip = P->clip_obs;
   int nenv = min(ENVS_PER_WAVE, N - env0);
-  const int NO = P->num_obs;
+  const int NO = NOBS ? NOBS : P->num_obs;
+  auto clamp4 = [&](float4 v) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip); return v; };
+  const bool full = (nenv == ENVS_PER_WAVE) && (reinterpret_cast<uintptr_t>(W.out_states) & 15) == 0;
+  if (!DR && NOBS && full) {
+    // a full wavefront without observation noise: 16 rows of obs (NOBS floats, a multiple of 4) and of states (93 floats; env0 is a multiple
+    // of 16: 5952-byte offsets) are contiguous blocks of float4.  Known trip counts: all LDS reads are issued before the first store
+    constexpr int NB = NOBS ? NOBS : 64, NV = ENVS_PER_WAVE * NB / 4, NS = ENVS_PER_WAVE * 93 / 4, KV = (NV + 63) / 64, KS = (NS + 63) / 64;
+    float4 vo[KV], vs[KS];
+#pragma unroll
+    for (int k = 0; k < KV; k++) { const int i = lane + 64 * k; vo[k] = reinterpret_cast<const float4*>(sObs)[(NV % 64 == 0 || i < NV) ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < KS; k++) { const int i = lane + 64 * k; vs[k] = reinterpret_cast<const float4*>(sSt)[(NS % 64 == 0 || i < NS) ? i : 0]; }
+    float4* ob = reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NB); float4* oo = reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NB);
+    float4* sb = reinterpret_cast<float4*>(W.states_buf + (size_t)env0 * 93); float4* so = reinterpret_cast<float4*>(W.out_states + (size_t)env0 * 93);
+#pragma unroll
+    for (int k = 0; k < KV; k++) { const int i = lane + 64 * k; if (NV % 64 == 0 || i < NV) { ob[i] = vo[k]; if (W.out_obs) oo[i] = clamp4(vo[k]); } }
+#pragma unroll
+    for (int k = 0; k < KS; k++) { const int i = lane + 64 * k; if (NS % 64 == 0 || i < NS) { sb[i] = vs[k]; if (W.out_states) so[i] = clamp4(vs[k]); } }
+  } else {
   // obs: nenv*NO floats contiguous (NO = 64 or 88, both multiples of 4)
   for (int i = lane; i < nenv * (NO / 4); i += 64) {
     float4 v = reinterpret_cast<const float4*>(sObs)[i];
@@ -972,16 +986,14 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
       v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
     }
     reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NO)[i] = v;
-    if (W.out_obs) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
-      reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NO)[i] = v; }
+    if (W.out_obs) reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NO)[i] = clamp4(v);
   }
   // states: 16 rows of 93 floats are one contiguous block of 372 float4 (env0 is a multiple of 16: 5952-byte offsets)
-  if (nenv == ENVS_PER_WAVE && (reinterpret_cast<uintptr_t>(W.out_states) & 15) == 0) {
+  if (full) {
     for (int i = lane; i < ENVS_PER_WAVE * 93 / 4; i += 64) {
       float4 v = reinterpret_cast<const float4*>(sSt)[i];
       reinterpret_cast<float4*>(W.states_buf + (size_t)env0 * 93)[i] = v;
-      if (W.out_states) { v.x = clampf(v.x, clip); v.y = clampf(v.y, clip); v.z = clampf(v.z, clip); v.w = clampf(v.w, clip);
-        reinterpret_cast<float4*>(W.out_states + (size_t)env0 * 93)[i] = v; }
+      if (W.out_states) reinterpret_cast<float4*>(W.out_states + (size_t)env0 * 93)[i] = clamp4(v);
     }
   } else {
     for (int i = lane; i < nenv * 93; i += 64) {
@@ -989,6 +1001,7 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
       W.states_buf[(size_t)env0 * 93 + i] = v;
       if (W.out_states) W.out_states[(size_t)env0 * 93 + i] = clampf(v, clip);
     }
+  }
   }
   if (active && limb == 0) {
     W.rew_buf[env] = O.rew;
@@ -1260,7 +1273,7 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   DrOut DO; DO.drc = A.drc; DO.seed = A.seed; DO.dr_step = dr_step; DO.rand_buf = dr_rand_buf; DO.reset_key = dr_reset_key;
   DO.sKey = reinterpret_cast<uint32_t*>(sStash);      // the stash is dead after the last sub-step
   LM_STAMP(8);      // state stores issued
-  write_outputs<DR, DEFER>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
+  write_outputs<DR, DEFER, (VAR == 1) ? LM_MAX_OBS : 64>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
   LM_STAMP(10);     // the reduction's round trips
 }
 

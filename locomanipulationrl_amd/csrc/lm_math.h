@@ -126,6 +126,19 @@ LM_DEV int quad_sum_i(int v) {
   v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
   return v;
 }
+// Sum over the wavefront of a value that is non-zero only in lane 3 of every quad (one value per env), returned wave-uniform.  Row shifts by
+// 4 and 8 lanes leave each 16-lane row's sum in its lane 15, row_bcast:15 / row_bcast:31 carry it across the rows into lane 63: four DPP
+// adds and a v_readlane, no LDS.  The additions pair up exactly as in the xor-butterfly (4, 8, 16, 32) the oracle restates:
+// ((v3 + v7) + (v11 + v15)) per row, then (R0 + R1) + (R2 + R3).
+#define LM_DPP_ADD(v, ctrl, row_mask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xF, true))
+LM_DEV float wave_sum_lane3(float v) {
+  LM_DPP_ADD(v, 0x114, 0xF);      // row_shr:4
+  LM_DPP_ADD(v, 0x118, 0xF);      // row_shr:8
+  LM_DPP_ADD(v, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+  LM_DPP_ADD(v, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef LM_DPP_ADD
 LM_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
 LM_DEV SV quad_sum(SV a) { return sv(quad_sum(a.w), quad_sum(a.v)); }
 
