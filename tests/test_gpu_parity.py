@@ -249,7 +249,7 @@ def test_full_size_invariants_4096(robot_model, engine_cls):
             assert int(c[4].max()) <= 299 and int(c[4].min()) >= 1 and int(c[1].max()) <= 17
             assert torch.equal(rs, c[3])
             total_resets += int(rs.sum())
-            # extras are the means of the per-env terms: the fused reduction (int64 accumulators + arrival ticket) is complete
+            # extras are the means of the per-env terms: the fused reduction (counted int64 accumulator words) is complete
             # across all 256 wavefronts / 8 XCDs
             tm = eng.terms[:7].double().mean(dim=1)
             assert (ex[:7].double() - tm).abs().max() < 1e-5 * max(1.0, float(tm.abs().max()))
