@@ -108,3 +108,28 @@ def test_config5_vertical_gnn_8192_rollout():
         ro.obs[0].copy_(ro.obs[T])
     assert resets > 0
     ro.close(); env.close()
+
+
+def test_extras_reduction_beyond_131040_wavefronts():
+    """The counted accumulator words of the extras reduction take at most 4095 arrivals: above 32 x 4095 wavefronts lm_create
+    doubles the first-level rows.  2.1 M envs = 131 251 wavefronts -> 64 rows; the means and the success-window counters must still be exact."""
+    from locomanipulationrl_amd.engine_config import loco_params
+    from locomanipulationrl_amd.lib import Engine
+    from locomanipulationrl_amd.model.robot_model import load_model
+    N = 2_100_010                                       # not a multiple of 16: the last wavefront is ragged too
+    ep = loco_params(); eng = Engine(load_model("quadruped_robot_v2"), [ep], N, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ex = torch.empty(13, device="cuda")
+    ns = nr = 0
+    for t in range(4):
+        a = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1
+        if t == 1: eng.cnt[4][::3] = ep.max_episode - 2      # a third of the envs time out in this step: 700 k resets, the window rolls over in the next
+        eng.step(a, out_extras=ex)
+        tm = eng.terms[:7].double().mean(dim=1)
+        assert (ex[:7].double() - tm).abs().max() < 1e-5 * max(1.0, float(tm.abs().max()))
+        # the window of quadruped_pose_control.py:618-633 restated on the host
+        if nr > ep.max_reset_counts: ns = nr = 0
+        ns += int(eng.cnt[2].sum()); nr += int(eng.cnt[3].sum())
+        assert int(eng.stats_i64[0]) == ns and int(eng.stats_i64[1]) == nr
+    assert eng.blowups == 0 and 0 < int(eng.stats_i64[1]) < 700_000      # resets were counted, and the window has rolled over
+    eng.close()
