@@ -1,79 +1,54 @@
-#!/usr/bin/env python3
-"""Time the reference's own task-layer torch code on CPU at N = 4096.
-
-Build-container only (needs /root/reference; nothing here travels to the GPU box or is imported by the product).
-Uses the placeholder harness of tools/gen_golden.py: the reference's pre_physics_step / get_observations /
-calculate_metrics / is_done run unmodified on CPU tensors fed with a synthetic read-back state.  The number is
-the cost of the part of the reference's step() that is NOT PhysX -- what the fused task layer of k_step replaces --
-and is recorded in DESIGN.md section 6; PhysX itself cannot be timed here.
-
-Run:  python -B tools/time_reference_task_layer.py [--envs 4096] [--iters 60] [--threads 8]
-"""
-import argparse
-import os
-import sys
-import time
-
-import torch
-
-sys.dont_write_bytecode = True
+"""SURVEY 8(d), last row: the reference's OWN task-layer torch code (a4-a6, a9-a11: pre_physics_step with its reset scatter, get_observations,
+calculate_metrics, is_done) timed on the CPU at 4096 envs - the part of the reference's step that is not PhysX, including the scipy round
+trips of utils/math.py.  Runs in the build container only (it imports /root/reference through the placeholder harness of tools/gen_golden.py);
+the number never runs on the GPU box and is no baseline of the engine - it bounds what the reference's Python adds to every step on a host.
+    python -B tools/time_reference_task_layer.py > profiles/r02_reference_task_layer_cpu.json"""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import gen_golden as G  # noqa: E402
+import torch
+import gen_golden as G
+
+assert os.path.isdir(G.REF_RL), "reference tree not present"
+G._install_placeholders()
+sys.path[:0] = [G.REF_RL, os.path.dirname(G.REF_RL)]
+N, T = 4096, 40
+acc = {}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--iters", type=int, default=60)
-    ap.add_argument("--threads", type=int, default=0, help="torch intra-op threads (0 = torch default)")
-    ap.add_argument("--kind", default="loco", choices=["loco", "mani", "loco_cc", "mani_cc", "loco_pc", "mani_pc"])
-    a = ap.parse_args()
-    assert os.path.isdir(G.REF_RL), "reference tree not present"
-    if a.threads:
-        torch.set_num_threads(a.threads)
-    G._install_placeholders()
-    sys.path[:0] = [G.REF_RL, os.path.dirname(G.REF_RL)]
-    N = a.envs
-    g = torch.Generator().manual_seed(1)
-    torch.manual_seed(1)
-    t = G.make_task(a.kind, N)
-    loco = a.kind.startswith("loco")
-    robot = t.robot_locomotion if loco else t.robot_manipulation
-    q0 = t.default_joint_positions_loco[:, :12] if loco else t.default_joint_positions_mani[:, :12]
-    acts = [(torch.rand(N, 12, generator=g) * 2 - 1) for _ in range(8)]
-
-    def readback():
-        robot.joint_positions = q0 + 0.25 * torch.randn(N, 12, generator=g)
-        robot.joint_velocities = 2.0 * torch.randn(N, 12, generator=g)
-        robot.joint_accelerations = 20.0 * torch.randn(N, 12, generator=g)
-        robot.tip_positions = 0.15 * torch.randn(N, 4, 3, generator=g)
-        robot.knee_positions = torch.cat((0.15 * torch.randn(N, 8, 2, generator=g), 0.10 + 0.03 * torch.randn(N, 8, 1, generator=g)), -1)
-        pos = torch.cat((0.05 * torch.randn(N, 2, generator=g), 0.13 + 0.02 * torch.randn(N, 1, generator=g)), -1)
-        quat = G._rand_unit_quat(g, N, small=0.25)
-        lin, ang = 0.3 * torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
-        if loco:
-            robot.base_positions, robot.base_quaternions = pos, quat
-            robot.base_linear_velocities, robot.base_angular_velocities = lin, ang
-        else:
-            flip = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(N, 1)
-            from omni.isaac.core.utils.torch.rotations import quat_mul
-            t.obj.pos, t.obj.quat, t.obj.lin, t.obj.ang = pos, quat_mul(quat, flip), lin, ang
-
-    def one(i):
-        t.pre_physics_step(acts[i % 8].clone())
-        t.progress_buf[:] += 1
-        t.get_observations(); t.calculate_metrics(); t.is_done()
-
-    for i in range(5):
-        readback(); one(i)
-    tot = 0.0
-    for i in range(a.iters):
-        readback()                               # synthetic state generation is outside the timed region
-        t0 = time.perf_counter(); one(i); tot += time.perf_counter() - t0
-    ms = tot / a.iters * 1e3
-    print({"kind": a.kind, "envs": N, "iters": a.iters, "torch_threads": torch.get_num_threads(),
-           "task_layer_ms_per_step": round(ms, 3), "env_steps_per_s_task_layer_only": round(N / ms * 1e3)})
+def timed(obj, name):
+    f = getattr(obj, name)
+    def w(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); acc.setdefault(name, []).append(time.perf_counter() - t0); return r
+    setattr(obj, name, w)
 
 
-if __name__ == "__main__":
-    main()
+out = {"envs": N, "calls": T, "torch_threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kinds": {}}
+for kind in ("loco", "mani"):
+    acc.clear()
+    make = G.make_task
+    def make_timed(k, n, make=make):
+        t = make(k, n)
+        for m in ("pre_physics_step", "get_observations", "calculate_metrics", "is_done"): timed(t, m)
+        return t
+    G.make_task = make_timed
+    try: d = G.gen_task(kind, N=N, T=T)
+    finally: G.make_task = make
+    ms = {k: 1e3 * sorted(v)[len(v) // 2] for k, v in acc.items()}
+    tot = sum(ms.values())
+    out["kinds"][kind] = {"median_ms_per_call": {k: round(v, 3) for k, v in ms.items()}, "task_layer_ms_per_step": round(tot, 3),
+                          "env_steps_per_s_task_layer_alone": round(N / (tot * 1e-3)), "resets_per_step_mean": float(d["reset_buf"].sum(1).mean())}
+# the scipy round trips on their own (utils/math.py:33-193)
+from utils.math import rand_quaternions, transform_vectors, rotate_orientations
+g = torch.Generator().manual_seed(0)
+q = G._rand_unit_quat(g, N); v = torch.randn(N, 3, generator=g); V = torch.randn(N, 4, 3, generator=g)
+def med(f, n=20):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+    return 1e3 * sorted(ts)[n // 2]
+out["utils_math_ms_at_4096"] = {"transform_vectors (4 points per env)": round(med(lambda: transform_vectors(q, v, V, "cpu")), 3),
+                                "rotate_orientations": round(med(lambda: rotate_orientations(q, q, "cpu")), 3),
+                                "rand_quaternions": round(med(lambda: rand_quaternions(N, -0.4, 0.4, -0.4, 0.4, -1.57, 1.57, "cpu")), 3)}
+out["note"] = ("the reference's Python task layer alone, without PhysX, costs this much host time per step at 4096 envs; the engine runs the same "
+               "arithmetic inside k_step (the whole step, physics included, takes 0.034 ms on the GPU)")
+print(json.dumps(out, indent=1))
