@@ -127,6 +127,7 @@ typedef enum {
  *                use params[0] and [split_env, n_envs) use params[1] (co-train layout,
  *                joint_locomanipulation.py:25-34); split_env must be a multiple of 16.
  *   seed       : stream seed of the in-kernel goal sampler (replaces torch.rand in utils/math.py:184)
+ * n_envs must be positive and below 2^25 (33 554 432) per engine: the width of the reset counts in the fused extras reduction; LM_EINVAL otherwise.
  * All envs start with reset_buf = 1 (rl_task.py:111).
  * The engine belongs to the device that is current in the calling thread here: every later call on the handle must be made with the
  * same device current (one process per GPU) and returns LM_EINVAL otherwise instead of launching on another GPU. */
