@@ -23,10 +23,23 @@
 #include "lm_internal.h"
 #include <new>
 
+#ifdef LM_GNN_STAMPS
+__device__ unsigned long long lm_gnn_stamp_out[512 * 64];
+extern "C" int lm_debug_gnn_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(lm_gnn_stamp_out), sizeof(lm_gnn_stamp_out)) == hipSuccess ? 0 : -1; }
+#endif
 __global__ void __launch_bounds__(256) k_gnn_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
                                                      float* __restrict__ mean, float* __restrict__ value, SampleArgs SA) {
   __shared__ GnnSmem G;
+#ifdef LM_GNN_STAMPS
+  if (threadIdx.x < 64) reinterpret_cast<unsigned long long*>(lm_gnn_stamp_lds)[threadIdx.x] = 0;
+  __syncthreads();
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_gnn_stamp_lds[threadIdx.x >> 6][15] = t0_; }
+#endif
   gnn_block<false>(obs, 0.f, B, blockIdx.x * GNN_SAMPLES, W, mean, value, SA, G, threadIdx.x);
+#ifdef LM_GNN_STAMPS
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x < 512) lm_gnn_stamp_out[blockIdx.x * 64 + threadIdx.x] = reinterpret_cast<unsigned long long*>(lm_gnn_stamp_lds)[threadIdx.x];
+#endif
 }
 
 // MLP policy forward (device code in lm_policy_dev.h): one block = 16 samples on the 4 wavefronts of a CU

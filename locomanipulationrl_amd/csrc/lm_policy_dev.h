@@ -18,7 +18,9 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // ELU with exp(x) - 1 on the hardware exponential (v_exp_f32): absolute error < 1e-7, against ~30 instructions for expm1f
-__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
+// No compare / select: e^x - 1 >= x everywhere, so ELU(x) is the median of (x, 0, e^x - 1) - x < e^x - 1 < 0 below zero, 0 < x < e^x - 1 above
+// (v_med3_f32; one instruction less per activation, and the activations are the VALU work that competes with the MFMAs of the policy tiles).
+__device__ __forceinline__ float elu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __expf(x) - 1.0f); }
 
 
 // ---- counter-based standard normal for the fused action sampling (same generator as lm_engine.hip dr_sample, stream 9)
@@ -192,12 +194,25 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
   if (SA.log_std) { lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32); if (valid && g == 0) SA.logp[smp] = lp; }
 }
 
+// Diagnostic build only (-DLM_GNN_STAMPS, tools/stamp_profile.py --gnn): GNN_STAMP(k) adds the shader cycles since the wavefront's previous stamp to
+// bucket k of its row of an LDS array that k_gnn_forward copies out.  No stamp exists in the product build.
+#ifdef LM_GNN_STAMPS
+__shared__ unsigned long long lm_gnn_stamp_lds[4][16];
+#define GNN_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if ((lane & 63) == 0) { lm_gnn_stamp_lds[WAVE][k] += t_ - lm_gnn_stamp_lds[WAVE][15]; lm_gnn_stamp_lds[WAVE][15] = t_; } } while (0)
+#else
+#define GNN_STAMP(k) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ GNN policy tile
 // (restates scripts/graph_model_orebot_ov.py:11-241; the mapping is described at the top of lm_policy.hip)
 #define GNN_NODES 13
 #define GNN_EDGES 24
 #define GNN_H 32
 #define GNN_SAMPLES 16
+#define GNN_Q_STRIDE 36                    // floats per (node, sample) row of Q in LDS: 32 features + 4 pad, the 16-byte accesses of a lane group fall on disjoint banks
+#define GNN_Q_BUF (GNN_NODES * GNN_SAMPLES * GNN_Q_STRIDE)
 
 // parameter block offsets (floats)
 #define OFF_IN1_W 0                      // (32,16)
@@ -260,6 +275,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
       for (int i = 0; i < 4; i++) bias1[mb][i] = b1[16 * mb + 4 * g + i];
     __builtin_amdgcn_sched_barrier(0);      // issue the loads here, not at their first use
   };
+  GNN_STAMP(0);
   load_stage1(0);
   f32x4 h[NC][2];            // features of the owned nodes, C layout: h[j][mb][i] = feature 16 mb + 4 g + i of sample n
   // ---- input layers (:97-104)
@@ -289,8 +305,39 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
       }
     }
   }
-  // ---- three message-passing layers.  The weights of a stage are loaded one stage ahead (they do not depend on activations): stage 2's
-  // while stage 1 computes, the next layer's stage 1 while stage 2 computes, the first layer's while the input layers run.
+  // ---- three message-passing layers.  Per layer: stage 1 = P = W1[:, 0:32] h + b1 (kept in registers: only the owner needs it) and
+  // Q = W1[:, 32:64] h (to LDS: the wavefronts that own the edge targets need it) of the owned nodes; stage 2 = messages along the edges that END
+  // in the owned nodes, z = ELU(P_tgt + Q_src), y = W2 z, max-aggregated.  Both stages consume their B operand in the accumulator's own
+  // feature order (k-step (mb', i) of lane group g = feature 16 mb' + 4 g + i; the weights are gathered in that order), so h, P and z never
+  // leave the registers and Q moves as 16-byte LDS accesses.  Q is double-buffered by layer parity: stage 1 of layer L+1 writes the other
+  // buffer while slower wavefronts still read layer L's, so there is ONE block barrier per layer (Q written -> Q read) and what a wavefront
+  // does between two barriers is stage 2 of a layer plus stage 1 of the next - 208 / 192 / 192 / 208 MFMAs, against 128 + 112 on the
+  // critical path with a barrier between the stages.  Weights are loaded a stage ahead (they do not depend on activations).
+  GNN_STAMP(1);      // input layers
+  f32x4 P[NC][2];
+  auto stage1 = [&](int layer) {
+    float* sQ = sPQ + (layer & 1) * GNN_Q_BUF;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 8; st++) {
+        const float bb = h[j][st >> 2][st & 3];
+#pragma unroll
+        for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ob4][st], bb, acc[ob4], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) P[j][mb][i] = acc[mb][i] + bias1[mb][i];
+        *reinterpret_cast<f32x4*>(sQ + (gnn_node(WAVE, j) * GNN_SAMPLES + n) * GNN_Q_STRIDE + 16 * mb + 4 * g) = acc[2 + mb];
+      }
+    }
+  };
+  stage1(0);
+  GNN_STAMP(2);
   for (int layer = 0; layer < 3; layer++) {
     const float* L = W + OFF_LAYER0 + layer * LAYER_STRIDE;
     const float* W2 = L + 2080; const float* b2 = L + 3104;
@@ -298,36 +345,16 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
 #pragma unroll
     for (int mb = 0; mb < 2; mb++) {
 #pragma unroll
-      for (int st = 0; st < 8; st++) wb[mb][st] = W2[(16 * mb + n) * 32 + 4 * st + g];
+      for (int st = 0; st < 8; st++) wb[mb][st] = W2[(16 * mb + n) * 32 + 16 * (st >> 2) + 4 * g + (st & 3)];
 #pragma unroll
       for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
     }
+    if (layer < 2) load_stage1(layer + 1);      // wa / bias1 of this layer are dead: P and Q are computed
     __builtin_amdgcn_sched_barrier(0);
-    // stage 1: P = W1[:, 0:32] h + b1, Q = W1[:, 32:64] h of the owned nodes -> LDS.
-    // output feature block ob4 (0,1 = P rows 0..31; 2,3 = Q rows 0..31); k-step (mb', i) reads h[.][mb'][i] = feature 16 mb' + 4 g + i
+    lds_barrier();                               // every wavefront has written this layer's Q (and is done reading the previous layer's)
+    GNN_STAMP(3);
     {
-#pragma unroll
-      for (int j = 0; j < NC; j++) {
-        f32x4 acc[4];
-#pragma unroll
-        for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < 8; st++) {
-          const float bb = h[j][st >> 2][st & 3];
-#pragma unroll
-          for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ob4][st], bb, acc[ob4], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ob4 = 0; ob4 < 4; ob4++)
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            sPQ[(gnn_node(WAVE, j) * 64 + 16 * ob4 + 4 * g + i) * GNN_SAMPLES + n] = acc[ob4][i] + ((ob4 < 2) ? bias1[ob4][i] : 0.f);
-      }
-    }
-    if (layer < 2) load_stage1(layer + 1);
-    lds_barrier();
-    // stage 2: messages along the edges that end in the owned nodes, max-aggregated
-    {
+      const float* sQ = sPQ + (layer & 1) * GNN_Q_BUF;
 #pragma unroll
       for (int j = 0; j < NC; j++) {
         const int tgt = gnn_node(WAVE, j);
@@ -337,11 +364,12 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
 #pragma unroll
         for (int k = 0; k < gnn_nin(tgt); k++) {
           const int src = gnn_in(tgt, k);
+          const float* qs = sQ + (src * GNN_SAMPLES + n) * GNN_Q_STRIDE + 4 * g;
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs), q1 = *reinterpret_cast<const f32x4*>(qs + 16);
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int st = 0; st < 8; st++) {
-            const int kk = 4 * st + g;
-            const float z = elu(sPQ[(tgt * 64 + kk) * GNN_SAMPLES + n] + sPQ[(src * 64 + 32 + kk) * GNN_SAMPLES + n]);
+            const float z = elu(P[j][st >> 2][st & 3] + ((st >> 2) ? q1[st & 3] : q0[st & 3]));
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], z, acc1, 0, 0, 0);
           }
@@ -352,7 +380,9 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
         for (int i = 0; i < 4; i++) { h[j][0][i] = elu(m0[i] + bias2[0][i]); h[j][1][i] = elu(m1[i] + bias2[1][i]); }
       }
     }
-    lds_barrier();       // every wavefront is done reading sPQ before the next layer overwrites it
+    GNN_STAMP(4);
+    if (layer < 2) stage1(layer + 1);            // into the other Q buffer: no barrier between a layer's stage 2 and the next layer's stage 1
+    GNN_STAMP(2);
   }
   // ---- heads (:215-241): action mean of joint node j = Linear(32,1)(h[1+j]); value = Linear(32,1)(max over nodes)
   float wact[2][4];
@@ -390,7 +420,9 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
   // wavefront 0's physics step right after this barrier.  lds_barrier() orders LDS traffic only, so the stores are drained first
   // (vmcnt(0): written through to the L2 the block's loads are served from); nothing else is in flight at this point of the tile.
   if (LDS_OBS && SA.log_std) __builtin_amdgcn_s_waitcnt(0x0F70);
+  GNN_STAMP(6);      // heads, sampling
   lds_barrier();
+  GNN_STAMP(7);
   if (WAVE != 0) return;
   float v = 0.f;
 #pragma unroll
@@ -415,7 +447,7 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
 }
 
 struct GnnSmem {
-  float sPQ[GNN_NODES * 64 * GNN_SAMPLES];          // [node][feature 0..63][sample]
+  float sPQ[2 * GNN_Q_BUF] __attribute__((aligned(16)));      // Q of the current / the next layer: [layer parity][node][sample][32 features + pad]
   float sHm[4 * 32 * GNN_SAMPLES];                  // per-wavefront node maxima for the value head
   float sLp[12 * GNN_SAMPLES];                      // per-action log-prob terms
 };

@@ -112,8 +112,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
     # -fno-slp-vectorize: packed fp32 pairs cost more v_mov / AGPR shuffles than they save here (measured: 56.0 -> 58.2 M env-steps/s)
     # -fno-hip-fp32-correctly-rounded-divide-sqrt: 1/x and sqrt as v_rcp / v_sqrt (1 ulp) instead of the ~10-instruction IEEE sequences
+    # -amdgpu-mfma-vgpr-form: the MFMA accumulators of the policy tiles live in ordinary VGPRs, so the VALU work on them (ELU, max aggregation,
+    # LDS stores) needs no v_accvgpr_read per element (504 of them in k_gnn_forward)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           "-fPIC", "-shared", src, src2, "-o", _SO]
+           "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", src, src2, "-o", _SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
