@@ -74,6 +74,7 @@ int lm_gnn_param_count(void) { return GNN_PARAMS; }
 
 int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream) {
   if (!obs || !params || !mean || !value || batch <= 0) return -1;
+  if (reinterpret_cast<uintptr_t>(params) & 15) return lm_internal_fail(-1, "lm_gnn_forward: the parameter block must be 16-byte aligned (its weight rows are read with 16-byte loads)");
   int blocks = (batch + GNN_SAMPLES - 1) / GNN_SAMPLES;
   SampleArgs SA{}; hipLaunchKernelGGL(k_gnn_forward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, obs, batch, params, mean, value, SA);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -137,6 +138,7 @@ int lm_rollout_create(lm_rollout** out, lm_engine* env, int policy, const float*
                       float* obs, float* actions, float* logp, float* values, float* rewards, int64_t* dones, float* extras) {
   if (!out || !env || !policy_params || !log_std || !obs || !actions || !logp || !values || !rewards || !dones || T <= 0) return lm_internal_fail(-1, "lm_rollout_create: null argument or T <= 0");
   if (policy != LM_POLICY_MLP && policy != LM_POLICY_GNN) return lm_internal_fail(-1, "lm_rollout_create: policy must be LM_POLICY_MLP or LM_POLICY_GNN");
+  if (policy == LM_POLICY_GNN && (reinterpret_cast<uintptr_t>(policy_params) & 15)) return lm_internal_fail(-1, "lm_rollout_create: the GNN parameter block must be 16-byte aligned");
   const int nobs = lm_num_obs(env);
   if (nobs != 64 && !(nobs == 88 && policy == LM_POLICY_MLP)) return lm_internal_fail(-1, "lm_rollout_create: the GNN needs 64-wide observations (the MLP takes 64 or 88)");      // the GNN reads the 64-wide layout; the MLP also the 88-wide one
   lm_rollout* r = new (std::nothrow) lm_rollout();

@@ -248,6 +248,11 @@ __device__ __forceinline__ constexpr int gnn_node(int w, int j) {
 __device__ __forceinline__ constexpr int gnn_nin(int t) { return t == 0 ? 4 : (t <= 8 ? 2 : 1); }
 __device__ __forceinline__ constexpr int gnn_in(int t, int k) { return t == 0 ? 1 + k : (t <= 4 ? (k == 0 ? 0 : t + 4) : (t <= 8 ? (k == 0 ? t - 4 : t + 4) : t - 4)); }
 
+// the incoming edges of a wavefront's nodes as one flat list (node after node): count, owning node slot, index among that node's edges
+__device__ __forceinline__ constexpr int gnn_ne(int w) { int c = 0; for (int j = 0; j < gnn_count(w); j++) c += gnn_nin(gnn_node(w, j)); return c; }
+__device__ __forceinline__ constexpr int gnn_ej(int w, int e) { int c = 0; for (int j = 0; j < gnn_count(w); j++) { const int nn = gnn_nin(gnn_node(w, j)); if (e < c + nn) return j; c += nn; } return 0; }
+__device__ __forceinline__ constexpr int gnn_ek(int w, int e) { int c = 0; for (int j = 0; j < gnn_count(w); j++) { const int nn = gnn_nin(gnn_node(w, j)); if (e < c + nn) return e - c; c += nn; } return 0; }
+
 // LDS_OBS = false: `obs` is the global (B, 64) observation matrix.  LDS_OBS = true: `obs` is a [16][64] tile in LDS with the UNCLIPPED
 // observations of samples s0 .. s0+15, clamped to +-obs_clip first (= the values the step kernel returns).  mean may be null.
 template <int WAVE, bool LDS_OBS>
@@ -263,19 +268,25 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
                          float v = (o - W[OFF_OBS_MEAN + c]) * W[OFF_OBS_ISTD + c]; return fminf(fmaxf(v, -oclip), oclip); };
 
   float wa[4][8], bias1[2][4];      // stage-1 weights of the current layer (A operand, gathered in the accumulator's k order)
+  // (four consecutive k-steps of an output block are four consecutive floats of a weight row: 16-byte loads)
   auto load_stage1 = [&](int layer) {
     const float* W1 = W + OFF_LAYER0 + layer * LAYER_STRIDE; const float* b1 = W1 + 2048;
 #pragma unroll
     for (int ob4 = 0; ob4 < 4; ob4++)
 #pragma unroll
-      for (int st = 0; st < 8; st++) wa[ob4][st] = W1[(16 * (ob4 & 1) + n) * 64 + 32 * (ob4 >> 1) + 16 * (st >> 2) + 4 * g + (st & 3)];
+      for (int q = 0; q < 2; q++) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W1 + (16 * (ob4 & 1) + n) * 64 + 32 * (ob4 >> 1) + 16 * q + 4 * g);
 #pragma unroll
-    for (int mb = 0; mb < 2; mb++)
+        for (int i = 0; i < 4; i++) wa[ob4][4 * q + i] = w4[i];
+      }
 #pragma unroll
-      for (int i = 0; i < 4; i++) bias1[mb][i] = b1[16 * mb + 4 * g + i];
+    for (int mb = 0; mb < 2; mb++) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1 + 16 * mb + 4 * g);
+#pragma unroll
+      for (int i = 0; i < 4; i++) bias1[mb][i] = b4[i];
+    }
     __builtin_amdgcn_sched_barrier(0);      // issue the loads here, not at their first use
   };
-  GNN_STAMP(0);
   load_stage1(0);
   f32x4 h[NC][2];            // features of the owned nodes, C layout: h[j][mb][i] = feature 16 mb + 4 g + i of sample n
   // ---- input layers (:97-104)
@@ -345,40 +356,66 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
 #pragma unroll
     for (int mb = 0; mb < 2; mb++) {
 #pragma unroll
-      for (int st = 0; st < 8; st++) wb[mb][st] = W2[(16 * mb + n) * 32 + 16 * (st >> 2) + 4 * g + (st & 3)];
+      for (int q = 0; q < 2; q++) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W2 + (16 * mb + n) * 32 + 16 * q + 4 * g);
 #pragma unroll
-      for (int i = 0; i < 4; i++) bias2[mb][i] = b2[16 * mb + 4 * g + i];
+        for (int i = 0; i < 4; i++) wb[mb][4 * q + i] = w4[i];
+      }
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(b2 + 16 * mb + 4 * g);
+#pragma unroll
+      for (int i = 0; i < 4; i++) bias2[mb][i] = b4[i];
     }
     if (layer < 2) load_stage1(layer + 1);      // wa / bias1 of this layer are dead: P and Q are computed
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();                               // every wavefront has written this layer's Q (and is done reading the previous layer's)
     GNN_STAMP(3);
     {
+      // Software-pipelined over the flat edge list: while the 16 MFMAs of edge e issue, the activations z of edge e+1 are computed and
+      // edge e-1 is max-aggregated (two accumulator sets), so the matrix pipe does not drain at every edge / node boundary.
+      // max_e ELU(y_e + b) = ELU(max_e y_e + b): ELU and the bias add are monotonic, so the activation is applied once per target node.
       const float* sQ = sPQ + (layer & 1) * GNN_Q_BUF;
+      constexpr int NE = gnn_ne(WAVE);
+      f32x4 acc[2][2], mx[NC][2];
 #pragma unroll
-      for (int j = 0; j < NC; j++) {
-        const int tgt = gnn_node(WAVE, j);
-        // max_e ELU(y_e + b) = ELU(max_e y_e + b): ELU and the bias add are monotonic, so the activation is applied once per target node
-        // instead of once per incoming edge (the VALU work of a wavefront is not hidden behind its own MFMAs -- tools/microbench/mfma_chains.hip)
-        f32x4 m0 = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, m1 = m0;
+      for (int j = 0; j < NC; j++) mx[j][0] = mx[j][1] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+      auto q_of = [&](int e, f32x4& q0, f32x4& q1) {
+        const int src = gnn_in(gnn_node(WAVE, gnn_ej(WAVE, e)), gnn_ek(WAVE, e));
+        const float* qs = sQ + (src * GNN_SAMPLES + n) * GNN_Q_STRIDE + 4 * g;
+        q0 = *reinterpret_cast<const f32x4*>(qs); q1 = *reinterpret_cast<const f32x4*>(qs + 16);
+      };
+      auto aggregate = [&](int e) {      // edge e is complete in acc[e & 1]
+        const int j = gnn_ej(WAVE, e);
 #pragma unroll
-        for (int k = 0; k < gnn_nin(tgt); k++) {
-          const int src = gnn_in(tgt, k);
-          const float* qs = sQ + (src * GNN_SAMPLES + n) * GNN_Q_STRIDE + 4 * g;
-          const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs), q1 = *reinterpret_cast<const f32x4*>(qs + 16);
-          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; i++) { mx[j][0][i] = fmaxf(mx[j][0][i], acc[e & 1][0][i]); mx[j][1][i] = fmaxf(mx[j][1][i], acc[e & 1][1][i]); }
+        if (gnn_ek(WAVE, e) == gnn_nin(gnn_node(WAVE, j)) - 1) {
 #pragma unroll
-          for (int st = 0; st < 8; st++) {
-            const float z = elu(P[j][st >> 2][st & 3] + ((st >> 2) ? q1[st & 3] : q0[st & 3]));
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], z, acc1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; i++) { m0[i] = fmaxf(m0[i], acc0[i]); m1[i] = fmaxf(m1[i], acc1[i]); }
+          for (int i = 0; i < 4; i++) { h[j][0][i] = elu(mx[j][0][i] + bias2[0][i]); h[j][1][i] = elu(mx[j][1][i] + bias2[1][i]); }
         }
+      };
+      float zc[8];
+      {
+        f32x4 q0, q1; q_of(0, q0, q1);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { h[j][0][i] = elu(m0[i] + bias2[0][i]); h[j][1][i] = elu(m1[i] + bias2[1][i]); }
+        for (int st = 0; st < 8; st++) zc[st] = elu(P[gnn_ej(WAVE, 0)][st >> 2][st & 3] + ((st >> 2) ? q1[st & 3] : q0[st & 3]));
       }
+#pragma unroll
+      for (int e = 0; e < NE; e++) {
+        f32x4 q0, q1; float zn[8];
+        if (e + 1 < NE) q_of(e + 1, q0, q1);
+        acc[e & 1][0] = acc[e & 1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+          acc[e & 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], zc[st], acc[e & 1][0], 0, 0, 0);
+          acc[e & 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], zc[st], acc[e & 1][1], 0, 0, 0);
+          if (e + 1 < NE) zn[st] = elu(P[gnn_ej(WAVE, e + 1)][st >> 2][st & 3] + ((st >> 2) ? q1[st & 3] : q0[st & 3]));
+          if (e >= 1 && st == 3) aggregate(e - 1);
+        }
+        if (e + 1 < NE) {
+#pragma unroll
+          for (int st = 0; st < 8; st++) zc[st] = zn[st];
+        }
+      }
+      aggregate(NE - 1);
     }
     GNN_STAMP(4);
     if (layer < 2) stage1(layer + 1);            // into the other Q buffer: no barrier between a layer's stage 2 and the next layer's stage 1
