@@ -487,12 +487,21 @@ struct GnnSmem {
   float sPQ[2 * GNN_Q_BUF] __attribute__((aligned(16)));      // Q of the current / the next layer: [layer parity][node][sample][32 features + pad]
   float sHm[4 * 32 * GNN_SAMPLES];                  // per-wavefront node maxima for the value head
   float sLp[12 * GNN_SAMPLES];                      // per-action log-prob terms
+  int rot;                                          // rotation of the wavefront -> node-set map of this block (gnn_block)
 };
 // forward of samples s0 .. s0+15 by the 256 threads of a block (contains block barriers)
 template <bool LDS_OBS>
 __device__ __forceinline__ void gnn_block(const float* obs, float obs_clip, int B, int s0, const float* __restrict__ W, float* __restrict__ mean,
                                           float* __restrict__ value, const SampleArgs& SA, GnnSmem& G, int t) {
-  const int wave = t >> 6, lane = t & 63;
+  const int lane = t & 63;
+  // Which node set a wavefront takes.  With two blocks on a compute unit (> 4096 samples), the two wavefronts that share a SIMD are the same
+  // wavefront index of the two blocks: the same node set in the same phase, the stage-2-heavy set {hub, ..} twice on one matrix pipe and the
+  // stage-1-heavy four-node set twice on another.  The second block of a compute unit (odd wave slot of its first wavefront, read from HW_ID)
+  // rotates its sets by two, pairing 112 + 96 and 80 + 96 MFMAs per stage on a SIMD instead of 112 + 112 and 128 + 128.  Any rotation is a
+  // valid assignment (the result does not depend on it); the block agrees on one through LDS.
+  if (t == 0) G.rot = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) * 2;      // hwreg(HW_REG_HW_ID, 0, 4) = WAVE_ID: this wavefront's slot on its SIMD
+  lds_barrier();
+  const int wave = ((t >> 6) + G.rot) & 3;
   if (wave == 0) gnn_body<0, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
   else if (wave == 1) gnn_body<1, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
   else if (wave == 2) gnn_body<2, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
