@@ -150,31 +150,30 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
       sX[(c0 + i) * MLP_LDS_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
     }
   }
-  float abuf[2][MLP_CH];
-  int cur = 0;
-  L1::issue(W1, wave, lane, 0, abuf[0]);
+  // The chunks of all layers form one sequence s = 0 .. NS-1 (the head's single chunk last, wavefront 0 only); chunk s+2 is issued before chunk
+  // s is computed, into a ring of three register buffers: two chunks (16 KB per wavefront) are in flight behind the MFMAs, because one
+  // chunk's 32 MFMAs (about 1000 cycles) do not cover an L2 round trip under the load of 1024 streaming wavefronts.
+  constexpr int N1 = L1::NCH, N2 = L2::NCH, N3 = L3::NCH, NB = N1 + N2 + N3;
+  auto issue = [&](int sq, float* dst) {
+    if (sq < N1) L1::issue(W1, wave, lane, sq, dst);
+    else if (sq < N1 + N2) L2::issue(W2, wave, lane, sq - N1, dst);
+    else if (sq < NB) L3::issue(W3, wave, lane, sq - N1 - N2, dst);
+    else if (sq == NB && wave == 0) L4::issue(W4, 0, lane, 0, dst);
+  };
+  float abuf[3][MLP_CH];
+  issue(0, abuf[0]); issue(1, abuf[1]);
   lds_barrier();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < L1::NCH; c++) {
-    if (c + 1 < L1::NCH) L1::issue(W1, wave, lane, c + 1, abuf[cur ^ 1]); else L2::issue(W2, wave, lane, 0, abuf[cur ^ 1]);
-    L1::compute(br1, sX, sH1, wave, n, g, true, c, abuf[cur], acc); cur ^= 1;
+  for (int sq = 0; sq < NB; sq++) {
+    issue(sq + 2, abuf[(sq + 2) % 3]);
+    if (sq < N1) L1::compute(br1, sX, sH1, wave, n, g, true, sq, abuf[sq % 3], acc);
+    else if (sq < N1 + N2) L2::compute(br2, sH1, sH2, wave, n, g, true, sq - N1, abuf[sq % 3], acc);
+    else L3::compute(br3, sH2, sH3, wave, n, g, true, sq - N1 - N2, abuf[sq % 3], acc);
+    if (sq == N1 - 1 || sq == N1 + N2 - 1 || sq == NB - 1) lds_barrier();
   }
-  lds_barrier();
-#pragma unroll
-  for (int c = 0; c < L2::NCH; c++) {
-    if (c + 1 < L2::NCH) L2::issue(W2, wave, lane, c + 1, abuf[cur ^ 1]); else L3::issue(W3, wave, lane, 0, abuf[cur ^ 1]);
-    L2::compute(br2, sH1, sH2, wave, n, g, true, c, abuf[cur], acc); cur ^= 1;
-  }
-  lds_barrier();
-#pragma unroll
-  for (int c = 0; c < L3::NCH; c++) {
-    if (c + 1 < L3::NCH) L3::issue(W3, wave, lane, c + 1, abuf[cur ^ 1]); else if (wave == 0) L4::issue(W4, 0, lane, 0, abuf[cur ^ 1]);
-    L3::compute(br3, sH2, sH3, wave, n, g, true, c, abuf[cur], acc); cur ^= 1;
-  }
-  lds_barrier();
   if (wave != 0) return;
-  L4::compute(br4, sH3, sO, 0, n, g, false, 0, abuf[cur], acc);
+  L4::compute(br4, sH3, sO, 0, n, g, false, 0, abuf[NB % 3], acc);
   __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
   const int smp = s0 + n;
   const bool valid = smp < B;
