@@ -1346,6 +1346,11 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
   __shared__ PolicySmem<NOBS, POLICY> PS;
   const int t = threadIdx.x, env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+#ifdef LM_STAMPS
+  if (threadIdx.x < 16) lm_stamp_lds[threadIdx.x] = 0;
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if (threadIdx.x == 0) lm_stamp_lds[15] = t0_; }
+  __syncthreads();
+#endif
   for (int k = 0; k <= R.T; k++) {
     // The loop body must be compiled like a stand-alone kernel: without these opaque copies the compiler hoists every loop-invariant
     // address (one 64-bit pointer per state row and per weight chunk) out of the loop and spills hundreds of registers to scratch.
@@ -1362,6 +1367,7 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
       if (k == 0) mlp_block<NOBS, false>(R.obs, 0.f, B.N, env0, Wk, nullptr, R.values, SA, reinterpret_cast<MlpSmem<NOBS>&>(PS.M), t);
       else mlp_block<NOBS, true>(sObs, Pk->clip_obs, B.N, env0, Wk, nullptr, R.values + (size_t)k * Nk, SA, reinterpret_cast<MlpSmem<NOBS>&>(PS.M), t);
     }
+    if (t < 64) LM_STAMP(13);      // diagnostic build: the policy tile as wavefront 0 sees it
     if (k == R.T) break;
     if (t < 64) {
       // (the counters and the state are written and read back by this same wavefront: program order.  The sampled actions too with the MLP;
@@ -1372,7 +1378,12 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
       step_dispatch(B, Pk, sTab, sObs, sSt, sStash);
     }
     lds_barrier();          // the observations staged in LDS are visible to the other wavefronts; global data is private to wavefront 0
+    if (t < 64) LM_STAMP(14);
   }
+#ifdef LM_STAMPS
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 16 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
+#endif
 }
 
 // extras and success windows of the T steps of a persistent rollout, in step order: the accumulator rows are fetched (and cleared) 64 steps

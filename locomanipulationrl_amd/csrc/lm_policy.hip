@@ -47,7 +47,16 @@ template <int NOBS>
 __global__ void __launch_bounds__(256) k_mlp_forward(const float* __restrict__ obs, int B, const float* __restrict__ W,
                                                      float* __restrict__ mean, float* __restrict__ value, SampleArgs SA) {
   __shared__ MlpSmem<NOBS> M;
+#ifdef LM_GNN_STAMPS
+  if (threadIdx.x < 64) reinterpret_cast<unsigned long long*>(lm_gnn_stamp_lds)[threadIdx.x] = 0;
+  __syncthreads();
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_gnn_stamp_lds[threadIdx.x >> 6][15] = t0_; }
+#endif
   mlp_block<NOBS, false>(obs, 0.f, B, blockIdx.x * 16, W, mean, value, SA, M, threadIdx.x);
+#ifdef LM_GNN_STAMPS
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x < 512) lm_gnn_stamp_out[blockIdx.x * 64 + threadIdx.x] = reinterpret_cast<unsigned long long*>(lm_gnn_stamp_lds)[threadIdx.x];
+#endif
 }
 
 extern "C" {

@@ -23,6 +23,17 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ float elu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __expf(x) - 1.0f); }
 
 
+#ifdef LM_GNN_STAMPS
+__shared__ unsigned long long lm_gnn_stamp_lds[4][16];      // diagnostic builds only (tools/stamp_profile_gnn.py)
+#endif
+#ifdef LM_GNN_STAMPS
+#define MLP_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (lane == 0) { lm_gnn_stamp_lds[wave][k] += t_ - lm_gnn_stamp_lds[wave][15]; lm_gnn_stamp_lds[wave][15] = t_; } } while (0)
+#else
+#define MLP_STAMP(k) do { } while (0)
+#endif
+
 // ---- counter-based standard normal for the fused action sampling (same generator as lm_engine.hip dr_sample, stream 9)
 __device__ __forceinline__ float ro_normal(uint32_t seed, uint32_t env, uint32_t key, uint32_t idx) {
   // actions 2p and 2p+1 are the cosine and sine branches of one Box-Muller pair
@@ -73,6 +84,7 @@ template <bool NATURAL> __device__ __forceinline__ int mlp_krow(int st, int g) {
 // computed and before the block barrier): the weight stream never drains and the kernel is bound by the matrix pipe, not by one
 // L2 round trip per chunk.
 #define MLP_CH 32
+#define MLP_RING 3      // register buffers of MLP_CH k-steps each: MLP_RING - 1 chunks in flight behind the MFMAs
 template <int OUT_BLOCKS, int IN_STEPS, bool NATURAL>
 struct MlpLayer {
   static constexpr int OWNED = (OUT_BLOCKS + 3) / 4, TOTAL = OWNED * IN_STEPS, NCH = (TOTAL + MLP_CH - 1) / MLP_CH;
@@ -160,20 +172,24 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
     else if (sq < NB) L3::issue(W3, wave, lane, sq - N1 - N2, dst);
     else if (sq == NB && wave == 0) L4::issue(W4, 0, lane, 0, dst);
   };
-  float abuf[3][MLP_CH];
-  issue(0, abuf[0]); issue(1, abuf[1]);
+  MLP_STAMP(0);      // biases, observation tile
+  float abuf[MLP_RING][MLP_CH];
+#pragma unroll
+  for (int sq = 0; sq < MLP_RING - 1; sq++) issue(sq, abuf[sq]);
   lds_barrier();
+  MLP_STAMP(1);      // first two chunks issued, barrier
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int sq = 0; sq < NB; sq++) {
-    issue(sq + 2, abuf[(sq + 2) % 3]);
-    if (sq < N1) L1::compute(br1, sX, sH1, wave, n, g, true, sq, abuf[sq % 3], acc);
-    else if (sq < N1 + N2) L2::compute(br2, sH1, sH2, wave, n, g, true, sq - N1, abuf[sq % 3], acc);
-    else L3::compute(br3, sH2, sH3, wave, n, g, true, sq - N1 - N2, abuf[sq % 3], acc);
-    if (sq == N1 - 1 || sq == N1 + N2 - 1 || sq == NB - 1) lds_barrier();
+    issue(sq + MLP_RING - 1, abuf[(sq + MLP_RING - 1) % MLP_RING]);
+    if (sq < N1) L1::compute(br1, sX, sH1, wave, n, g, true, sq, abuf[sq % MLP_RING], acc);
+    else if (sq < N1 + N2) L2::compute(br2, sH1, sH2, wave, n, g, true, sq - N1, abuf[sq % MLP_RING], acc);
+    else L3::compute(br3, sH2, sH3, wave, n, g, true, sq - N1 - N2, abuf[sq % MLP_RING], acc);
+    MLP_STAMP(2 + (sq < N1 ? 0 : sq < N1 + N2 ? 2 : 4));      // compute of a layer's chunks
+    if (sq == N1 - 1 || sq == N1 + N2 - 1 || sq == NB - 1) { lds_barrier(); MLP_STAMP(3 + (sq < N1 ? 0 : sq < N1 + N2 ? 2 : 4)); }      // its barrier
   }
   if (wave != 0) return;
-  L4::compute(br4, sH3, sO, 0, n, g, false, 0, abuf[NB % 3], acc);
+  L4::compute(br4, sH3, sO, 0, n, g, false, 0, abuf[NB % MLP_RING], acc);
   __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
   const int smp = s0 + n;
   const bool valid = smp < B;
@@ -191,12 +207,12 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
     }
   }
   if (SA.log_std) { lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32); if (valid && g == 0) SA.logp[smp] = lp; }
+  MLP_STAMP(8);      // head + sampling (wavefront 0)
 }
 
 // Diagnostic build only (-DLM_GNN_STAMPS, tools/stamp_profile.py --gnn): GNN_STAMP(k) adds the shader cycles since the wavefront's previous stamp to
 // bucket k of its row of an LDS array that k_gnn_forward copies out.  No stamp exists in the product build.
 #ifdef LM_GNN_STAMPS
-__shared__ unsigned long long lm_gnn_stamp_lds[4][16];
 #define GNN_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     if ((lane & 63) == 0) { lm_gnn_stamp_lds[WAVE][k] += t_ - lm_gnn_stamp_lds[WAVE][15]; lm_gnn_stamp_lds[WAVE][15] = t_; } } while (0)
