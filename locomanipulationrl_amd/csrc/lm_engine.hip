@@ -21,6 +21,25 @@
 #include "lm_rng.h"
 #include "../../include/lm_engine.h"
 #include "../../include/lm_policy.h"
+// Diagnostic build only (-DLM_STAMPS, tools/stamp_profile.sh): LM_STAMP(k) adds the shader cycles since the previous stamp to bucket k of
+// a per-workgroup LDS array that k_step copies to lm_stamp_out.  No stamp exists in the product build.
+#ifdef LM_STAMPS
+__device__ unsigned long long lm_stamp_out[1024 * 64];
+__shared__ unsigned long long lm_stamp_lds[64];      // 0..15: wavefront 0 (15 = its last stamp time); 16 (w - 1) + 16 ..: policy wavefront w of k_rollout_mlp
+#define LM_PSTAMP(w, k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if ((threadIdx.x & 63) == 0) { lm_stamp_lds[16 * (w) + (k)] += t_ - lm_stamp_lds[16 * (w) + 15]; lm_stamp_lds[16 * (w) + 15] = t_; } } while (0)
+#if LM_STAMPS == 2      // only the wavefront's lifetime (two clock reads around the whole body): what the product code takes inside the kernel
+#define LM_STAMP(k) do { } while (0)
+#else
+#define LM_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (threadIdx.x == 0) { lm_stamp_lds[k] += t_ - lm_stamp_lds[15]; lm_stamp_lds[15] = t_; } } while (0)
+#endif
+#define MLP_RES_STAMP(P, k) LM_PSTAMP((P) + 1, k)
+#else
+#define LM_STAMP(k) do { } while (0)
+#endif
 #include "lm_policy_dev.h"
 #include "lm_internal.h"
 
@@ -457,21 +476,6 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
   a = sv(v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y)); b = sv(v3(t1.z, t1.w, t2.x), v3(t2.y, t2.z, t2.w)); c = sv(v3(t3.x, t3.y, t3.z), v3(t3.w, t4.x, t4.y));
 }
 
-// Diagnostic build only (-DLM_STAMPS, tools/stamp_profile.sh): LM_STAMP(k) adds the shader cycles since the previous stamp to bucket k of
-// a per-workgroup LDS array that k_step copies to lm_stamp_out.  No stamp exists in the product build.
-#ifdef LM_STAMPS
-__device__ unsigned long long lm_stamp_out[1024 * 16];
-__shared__ unsigned long long lm_stamp_lds[16];
-#if LM_STAMPS == 2      // only the wavefront's lifetime (two clock reads around the whole body): what the product code takes inside the kernel
-#define LM_STAMP(k) do { } while (0)
-#else
-#define LM_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    if (threadIdx.x == 0) { lm_stamp_lds[k] += t_ - lm_stamp_lds[15]; lm_stamp_lds[15] = t_; } } while (0)
-#endif
-#else
-#define LM_STAMP(k) do { } while (0)
-#endif
 
 // One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
 // robot base is fixed at (Rb, pb).
@@ -1285,8 +1289,9 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   const int env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
 #ifdef LM_STAMPS
-  if (threadIdx.x < 16) lm_stamp_lds[threadIdx.x] = 0;
-  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if (threadIdx.x == 0) lm_stamp_lds[15] = t0_; }
+  if (threadIdx.x < 64) lm_stamp_lds[threadIdx.x] = 0;
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_stamp_lds[16 * (threadIdx.x >> 6) + 15] = t0_; }
   LM_STAMP(11); LM_STAMP(12);      // two stamps back to back: bucket 12 = the cost of a stamp
   const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1297,7 +1302,7 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   { const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime(), mt1_ = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { lm_stamp_lds[13] = mt1_ - mt0_; lm_stamp_lds[14] = rt1_ - rt0_; } }
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  if (threadIdx.x < 16 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 16 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
+  if (threadIdx.x < 64 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 64 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
 #endif
 }
 
@@ -1347,8 +1352,9 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
   const int t = threadIdx.x, env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
 #ifdef LM_STAMPS
-  if (threadIdx.x < 16) lm_stamp_lds[threadIdx.x] = 0;
-  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if (threadIdx.x == 0) lm_stamp_lds[15] = t0_; }
+  if (threadIdx.x < 64) lm_stamp_lds[threadIdx.x] = 0;
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_stamp_lds[16 * (threadIdx.x >> 6) + 15] = t0_; }
   __syncthreads();
 #endif
   for (int k = 0; k <= R.T; k++) {
@@ -1382,7 +1388,71 @@ __global__ void __launch_bounds__(256) k_rollout(StepArgs A, RolloutDev R) {
   }
 #ifdef LM_STAMPS
   __syncthreads();
-  if (threadIdx.x < 16 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 16 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
+  if (threadIdx.x < 64 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 64 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
+#endif
+}
+
+// ---- persistent rollout with the MLP policy: wavefront-specialised.  Wavefront 0 steps the physics; wavefronts 1..3 hold the policy's weights
+// in registers for the whole rollout and run the forward + sampling between two physics steps (lm_policy_dev.h mlp_res_tile).  The two roles
+// are separate loops (separate live ranges: the 300 weight registers of a policy wavefront never meet the physics' 440) that meet at block
+// barriers: MLP_RES_BARRIERS inside a forward, one after the physics step (observations staged in LDS).
+template <int NOBS, int P>
+LM_DEV void rollout_policy_loop(const StepArgs& A, const RolloutDev& R, const lm_params* P_, float* sObs, MlpSmem<NOBS>& M, int env0, int tp) {
+  MlpResRegs<NOBS, P> RG; RG.load(R.params, tp & 63, (tp & 63) >> 4);
+  const size_t N = (size_t)A.N;
+  const float clip_obs = P_->clip_obs;
+  for (int k = 0; k <= R.T; k++) {
+    SampleArgs SA{};
+    if (k < R.T) { SA.log_std = R.log_std; SA.cnt = A.cnt; SA.seed = R.noise_seed; SA.actions = R.actions + (size_t)k * N * 12; SA.logp = R.logp + (size_t)k * N; }
+    if (k == 0) mlp_res_tile<NOBS, P, false>(R.obs, 0.f, A.N, env0, R.params, RG, R.values, SA, M, tp);
+    else mlp_res_tile<NOBS, P, true>(sObs, clip_obs, A.N, env0, R.params, RG, R.values + (size_t)k * N, SA, M, tp);
+    if (k == R.T) break;
+    lds_barrier();          // the physics step of this iteration is done: observations in LDS, counters in memory
+  }
+}
+
+template <int NOBS>
+__global__ void __launch_bounds__(256) k_rollout_mlp(StepArgs A, RolloutDev R) {
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
+  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
+  __shared__ float4 sStash[STASH_SLOTS * 64];
+  __shared__ MlpSmem<NOBS> M;
+  const int t = threadIdx.x, env0 = lm_block() * ENVS_PER_WAVE;
+  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+#ifdef LM_STAMPS
+  if (threadIdx.x < 64) lm_stamp_lds[threadIdx.x] = 0;
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_stamp_lds[16 * (threadIdx.x >> 6) + 15] = t0_; }
+  __syncthreads();
+#endif
+  if (t < 64) {
+    for (int k = 0; k <= R.T; k++) {
+#pragma unroll
+      for (int b = 0; b < MLP_RES_BARRIERS; b++) lds_barrier();      // the policy wavefronts' forward k
+      LM_STAMP(13);
+      if (k == R.T) break;
+      // (as in k_rollout: the loop body compiled like a stand-alone kernel)
+      int z = 0; asm volatile("" : "+s"(z));
+      StepArgs B = A; B.state = A.state + z; B.cnt = A.cnt + z; B.N = A.N + z;
+      const lm_params* Pk = P + z; const size_t Nk = (size_t)B.N;
+      B.actions = R.actions + (size_t)k * Nk * 12; B.goal_rand = nullptr;
+      B.W.out_obs = R.obs + (size_t)(k + 1) * Nk * NOBS; B.W.out_states = nullptr; B.W.out_rew = R.rewards + (size_t)k * Nk;
+      B.W.out_resets = R.dones + (size_t)k * Nk; B.W.out_extras = nullptr; B.W.acc = R.acc_steps + 16 * k;
+      step_dispatch(B, Pk, sTab, sObs, sSt, sStash);
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // the counters that key the next action noise are in the L2 before the sampling wavefront reads them
+      lds_barrier();
+      LM_STAMP(14);
+    }
+  } else {
+    const int tp = t - 64;
+    if (tp < 64) rollout_policy_loop<NOBS, 0>(A, R, P, sObs, M, env0, tp);
+    else if (tp < 128) rollout_policy_loop<NOBS, 1>(A, R, P, sObs, M, env0, tp);
+    else rollout_policy_loop<NOBS, 2>(A, R, P, sObs, M, env0, tp);
+  }
+#ifdef LM_STAMPS
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 64 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
 #endif
 }
 
@@ -1887,7 +1957,10 @@ int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStr
   StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   RolloutDev D; D.params = R.params; D.log_std = R.log_std; D.obs = R.obs; D.actions = R.actions; D.logp = R.logp; D.values = R.values;
   D.rewards = R.rewards; D.dones = R.dones; D.acc_steps = R.acc_steps; D.T = R.T; D.noise_seed = R.noise_seed;
-  if (policy == LM_POLICY_MLP && R.nobs == 64) hipLaunchKernelGGL((k_rollout<64, LM_POLICY_MLP>), dim3(h->nblocks), dim3(256), 0, s, A, D);
+  static const bool streaming = getenv("LM_ROLLOUT_STREAMING_MLP") != nullptr;      // kernel experiments: the four-wavefront tile with streamed weights
+  if (policy == LM_POLICY_MLP && R.nobs == 64 && !streaming) hipLaunchKernelGGL(k_rollout_mlp<64>, dim3(h->nblocks), dim3(256), 0, s, A, D);
+  else if (policy == LM_POLICY_MLP && R.nobs == LM_MAX_OBS && !streaming) hipLaunchKernelGGL(k_rollout_mlp<LM_MAX_OBS>, dim3(h->nblocks), dim3(256), 0, s, A, D);
+  else if (policy == LM_POLICY_MLP && R.nobs == 64) hipLaunchKernelGGL((k_rollout<64, LM_POLICY_MLP>), dim3(h->nblocks), dim3(256), 0, s, A, D);
   else if (policy == LM_POLICY_MLP && R.nobs == LM_MAX_OBS) hipLaunchKernelGGL((k_rollout<LM_MAX_OBS, LM_POLICY_MLP>), dim3(h->nblocks), dim3(256), 0, s, A, D);
   else if (policy == LM_POLICY_GNN && R.nobs == 64) hipLaunchKernelGGL((k_rollout<64, LM_POLICY_GNN>), dim3(h->nblocks), dim3(256), 0, s, A, D);
   else return -1;

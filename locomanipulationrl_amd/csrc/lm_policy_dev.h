@@ -74,6 +74,9 @@ __host__ __device__ constexpr int mlp_params(int nobs) { return mlp_off_bh(nobs)
 // wavefronts, activations pass from layer to layer through LDS as [feature][sample] (row stride 20 floats: the B-operand reads of the
 // four lane groups then fall on disjoint banks).  Weights are the MFMA A operand, pre-permuted on the host (policies/mlp_model.py).
 #define MLP_LDS_STRIDE 20
+// the observation tile is read in natural k order (rows 4 st + g): stride 16 puts the four lane groups on banks 0-15 / 16-31 / 32-47 / 48-63
+#define MLP_X_STRIDE 16
+#define MLP_IN_STRIDE(NATURAL) ((NATURAL) ? MLP_X_STRIDE : MLP_LDS_STRIDE)
 // k-row of the B operand for k-step `st`, lane group g: layer 1 reads the observation in natural order, the later layers in the order
 // the host permutation assumes (16 (st >> 2) + 4 g + (st & 3), i.e. "the previous layer's accumulator tile")
 template <bool NATURAL> __device__ __forceinline__ int mlp_krow(int st, int g) { return NATURAL ? 4 * st + g : 16 * (st >> 2) + 4 * g + (st & 3); }
@@ -114,7 +117,7 @@ struct MlpLayer {
       const int s = c * MLP_CH + i;
       if (s < TOTAL) {
         const int j = s / IN_STEPS, st = s - j * IN_STEPS, mb = wave + 4 * j;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], sIn[mlp_krow<NATURAL>(st, g) * MLP_LDS_STRIDE + n], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], sIn[mlp_krow<NATURAL>(st, g) * MLP_IN_STRIDE(NATURAL) + n], acc, 0, 0, 0);
         if (st == IN_STEPS - 1) {
 #pragma unroll
           for (int k = 0; k < 4; k++) { float v = acc[k] + breg[4 * j + k]; sOut[(16 * mb + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
@@ -127,7 +130,7 @@ struct MlpLayer {
 
 
 template <int NOBS>
-struct MlpSmem { float sX[NOBS * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2[128 * MLP_LDS_STRIDE], sH3[64 * MLP_LDS_STRIDE], sO[16 * MLP_LDS_STRIDE]; };
+struct MlpSmem { float sX[NOBS * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2[128 * MLP_LDS_STRIDE], sH3[64 * MLP_LDS_STRIDE], sO[16 * MLP_LDS_STRIDE], sLp[12 * 16]; };
 
 // Forward pass of samples s0 .. s0+15 by the 256 threads of a block (t = thread index in the block; contains block barriers).
 // LDS_OBS = false: `obs` is the global (B, NOBS) observation matrix.  LDS_OBS = true: `obs` is a [16][NOBS] tile in LDS holding the
@@ -159,7 +162,7 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       float v = (o[i] - W[mlp_off_mean(NOBS) + c0 + i]) * W[mlp_off_istd(NOBS) + c0 + i];
-      sX[(c0 + i) * MLP_LDS_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
+      sX[(c0 + i) * MLP_X_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
     }
   }
   // The chunks of all layers form one sequence s = 0 .. NS-1 (the head's single chunk last, wavefront 0 only); chunk s+2 is issued before chunk
@@ -208,6 +211,141 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
   }
   if (SA.log_std) { lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32); if (valid && g == 0) SA.logp[smp] = lp; }
   MLP_STAMP(8);      // head + sampling (wavefront 0)
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP tile with RESIDENT weights (persistent rollout kernel, lm_engine.hip k_rollout_mlp).  The streaming tile above spends half of its time
+// waiting for its 233 KB of weights (all 256 compute units read the same rows at the same time), every step again.  In the persistent kernel
+// wavefront 0 steps the physics and the other three - the policy wavefronts P = 0, 1, 2 - are idle meanwhile with 512 registers per lane each:
+// they load every weight ONCE per rollout and keep it in registers (320 / 304 / 288 per lane), so a forward is MFMAs and LDS traffic only.
+// Output blocks are dealt to the policy wavefronts round-robin (layer 3: {0}, {1}, {2, 3}; the head, 16 MFMAs, is computed by each of them, so
+// that the action sampling - a Philox draw, a logarithm and a sine / cosine per action - is spread over all 192 lanes, one action each);
+// the k-step order inside an output block is that of the streaming tile, so both produce the same bits.
+template <int P, int OUT_BLOCKS, bool LAYER3> struct ResOwn {
+  static constexpr int CNT = LAYER3 ? (P == 2 ? 2 : 1) : (OUT_BLOCKS == 1 ? 1 : (OUT_BLOCKS - P + 2) / 3);      // the head (one block, 16 k-steps) is computed by all three
+  static __device__ __forceinline__ constexpr int mb(int j) { return LAYER3 ? (P == 2 ? 2 + j : P) : (OUT_BLOCKS == 1 ? 0 : P + 3 * j); }
+};
+template <int P, int OUT_BLOCKS, int IN_STEPS, bool NATURAL, bool LAYER3>
+struct ResLayer {
+  typedef ResOwn<P, OUT_BLOCKS, LAYER3> O;
+  static constexpr int CNT = O::CNT, NW = (CNT * IN_STEPS > 0) ? CNT * IN_STEPS : 1, NBR = CNT > 0 ? 4 * CNT : 1;
+  static __device__ __forceinline__ void load(const float* __restrict__ Wp, const float* __restrict__ bias, int lane, int g, float* w, float* br) {
+#pragma unroll
+    for (int j = 0; j < CNT; j++) {
+#pragma unroll
+      for (int st = 0; st < IN_STEPS; st++) w[j * IN_STEPS + st] = Wp[((size_t)O::mb(j) * IN_STEPS + st) * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < 4; k++) br[4 * j + k] = bias[16 * O::mb(j) + 4 * g + k];
+    }
+  }
+  static __device__ __forceinline__ void compute(const float* w, const float* br, const float* sIn, float* sOut, int n, int g, bool act) {
+    // the layer's input (the B operands of every output block) in registers first: read where they are used, each LDS round trip is exposed
+    // behind two k-steps of MFMAs (48 cycles per MFMA measured instead of 32)
+    float bv[IN_STEPS];
+#pragma unroll
+    for (int st = 0; st < IN_STEPS; st++) bv[st] = sIn[mlp_krow<NATURAL>(st, g) * MLP_IN_STRIDE(NATURAL) + n];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CNT; j++) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < IN_STEPS; st++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j * IN_STEPS + st], bv[st], acc, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const float v = acc[k] + br[4 * j + k]; sOut[(16 * O::mb(j) + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
+    }
+  }
+};
+#ifndef MLP_RES_STAMP
+#define MLP_RES_STAMP(P, k) do { } while (0)      // diagnostic builds of lm_engine.hip define it (tools/stamp_profile_rollout.py)
+#endif
+#define MLP_RES_BARRIERS 5      // block barriers inside one resident tile; the physics wavefront executes the same number while the tile runs
+
+template <int NOBS, int P> struct MlpResRegs {
+  typedef ResLayer<P, 16, NOBS / 4, true, false> L1; typedef ResLayer<P, 8, 64, false, false> L2; typedef ResLayer<P, 4, 32, false, true> L3; typedef ResLayer<P, 1, 16, false, false> L4;
+  float w1[L1::NW], w2[L2::NW], w3[L3::NW], w4[L4::NW], b1[L1::NBR], b2[L2::NBR], b3[L3::NBR], b4[L4::NBR];
+  __device__ __forceinline__ void load(const float* __restrict__ W, int lane, int g) {
+    L1::load(W + mlp_off_w1(NOBS), W + mlp_off_b1(NOBS), lane, g, w1, b1); L2::load(W + mlp_off_w2(NOBS), W + mlp_off_b2(NOBS), lane, g, w2, b2);
+    L3::load(W + mlp_off_w3(NOBS), W + mlp_off_b3(NOBS), lane, g, w3, b3); L4::load(W + mlp_off_wh(NOBS), W + mlp_off_bh(NOBS), lane, g, w4, b4);
+  }
+};
+
+// one forward of samples s0 .. s0+15 by the policy wavefronts; tp = 0 .. 191 the thread index among them.  Same arithmetic, same order as mlp_block.
+template <int NOBS, int P, bool LDS_OBS>
+__device__ __forceinline__ void mlp_res_tile(const float* obs, float obs_clip, int B, int s0, const float* __restrict__ W, const MlpResRegs<NOBS, P>& R,
+                                             float* __restrict__ value, const SampleArgs& SA, MlpSmem<NOBS>& M, int tp) {
+  typedef MlpResRegs<NOBS, P> RG;
+  float *sX = M.sX, *sH1 = M.sH1, *sH2 = M.sH2, *sH3 = M.sH3, *sO = M.sO;
+  const int lane = tp & 63, n = lane & 15, g = lane >> 4;
+  for (int idx = tp; idx < 16 * (NOBS / 4); idx += 192) {
+    const int sm = idx / (NOBS / 4), c0 = (idx - sm * (NOBS / 4)) * 4, sample = min(s0 + sm, B - 1);
+    float4 o4;
+    if (LDS_OBS) {
+      o4 = *reinterpret_cast<const float4*>(obs + sm * NOBS + c0);
+      o4.x = fminf(fmaxf(o4.x, -obs_clip), obs_clip); o4.y = fminf(fmaxf(o4.y, -obs_clip), obs_clip);
+      o4.z = fminf(fmaxf(o4.z, -obs_clip), obs_clip); o4.w = fminf(fmaxf(o4.w, -obs_clip), obs_clip);
+    } else {
+      o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * NOBS + c0);
+    }
+    const float clip = W[mlp_off_clip(NOBS)], o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float v = (o[i] - W[mlp_off_mean(NOBS) + c0 + i]) * W[mlp_off_istd(NOBS) + c0 + i];
+      sX[(c0 + i) * MLP_X_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
+    }
+  }
+  MLP_RES_STAMP(P, 0);      // wait for the physics + observation tile
+  lds_barrier();
+  MLP_RES_STAMP(P, 1);
+  RG::L1::compute(R.w1, R.b1, sX, sH1, n, g, true);
+  MLP_RES_STAMP(P, 2);
+  lds_barrier();
+  MLP_RES_STAMP(P, 3);
+  RG::L2::compute(R.w2, R.b2, sH1, sH2, n, g, true);
+  MLP_RES_STAMP(P, 4);
+  lds_barrier();
+  MLP_RES_STAMP(P, 5);
+  RG::L3::compute(R.w3, R.b3, sH2, sH3, n, g, true);
+  MLP_RES_STAMP(P, 6);
+  lds_barrier();
+  MLP_RES_STAMP(P, 7);
+  {
+    // head: rows 0..11 action means, 12 value; lane (n, g) holds rows 4g .. 4g+3 of sample n
+    float bv[16];
+#pragma unroll
+    for (int st = 0; st < 16; st++) bv[st] = sH3[mlp_krow<false>(st, g) * MLP_LDS_STRIDE + n];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 16; st++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.w4[st], bv[st], acc, 0, 0, 0);
+    float hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hv[k] = acc[k] + R.b4[k];
+    const int smp = s0 + n;
+    const bool valid = smp < B;
+    if (P == 2 && g == 3 && valid) value[smp] = hv[0];
+    // one action per lane: lane group g < 3 of wavefront P samples action 4g + P, lane group 3 samples action 4P + 3 (its mean lives in lane group P)
+    const float m3 = __shfl(hv[3], n + 16 * P);
+    const int j = (g < 3) ? 4 * g + P : 4 * P + 3;
+    const float v = (g < 3) ? hv[P] : m3;
+    if (SA.log_std && valid) {
+      const float ls = SA.log_std[j], eps = ro_normal(SA.seed, (uint32_t)smp, ro_key(SA.cnt, B, smp), (uint32_t)j);
+      SA.actions[(size_t)smp * 12 + j] = fmaf(expf(ls), eps, v);
+      M.sLp[j * 16 + n] = -0.5f * eps * eps - ls - 0.9189385332046727f;          // log N(a; mean, std) with (a - mean) / std = eps
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // the sampled actions are in the L2 before the physics wavefront is released to read them
+  }
+  MLP_RES_STAMP(P, 8);      // head + sampling
+  lds_barrier();
+  MLP_RES_STAMP(P, 9);
+  if (P == 2 && SA.log_std && g == 0 && s0 + n < B) {      // (while the physics runs) the log-probability, summed in the order of the streaming tile / k_sample_actions
+    float L[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { float lp = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) lp += M.sLp[(4 * q + i) * 16 + n];
+      L[q] = lp; }
+    SA.logp[s0 + n] = (L[0] + L[1]) + (L[2] + 0.f);
+  }
 }
 
 // Diagnostic build only (-DLM_GNN_STAMPS, tools/stamp_profile.py --gnn): GNN_STAMP(k) adds the shader cycles since the wavefront's previous stamp to

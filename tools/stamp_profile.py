@@ -34,9 +34,9 @@ for name, params, N in (("loco_4096", loco_params(), 4096), ("mani_4096", mani_p
     torch.cuda.synchronize(); import time; t0 = time.perf_counter()
     for i in range(1000): eng.step(acts[i % 50])
     torch.cuda.synchronize(); period_us = (time.perf_counter() - t0) / 1000 * 1e6
-    buf = np.zeros(1024 * 16, dtype=np.uint64)
+    buf = np.zeros(1024 * 64, dtype=np.uint64)
     assert lib.lm_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
-    b = buf.reshape(1024, 16)[: min(1024, N // 16)].astype(np.float64)
+    b = buf.reshape(1024, 64)[: min(1024, N // 16)].astype(np.float64)
     stamp = float(np.median(b[:, 12])); nst = {0: 1, 1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 1, 7: 1, 8: 1, 9: 1, 10: 1}
     med = {k: float(np.median(b[:, k])) for k in nst}
     tot = sum(med.values())

@@ -24,11 +24,13 @@ ro = Rollout(eng, kind, packed, log_std, T, noise_seed=3); ro.obs[0] = o0
 for _ in range(6):
     ro.run(use_graph="persistent"); ro.obs[0].copy_(ro.obs[T])
 torch.cuda.synchronize()
-buf = np.zeros(1024 * 16, dtype=np.uint64)
+buf = np.zeros(1024 * 64, dtype=np.uint64)
 assert lib.lm_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
-b = buf.reshape(1024, 16)[: N // 16].astype(np.float64) / T
+b = buf.reshape(1024, 64)[: N // 16].astype(np.float64) / T
 med = np.median(b, axis=0)
 names = {13: "policy tile (wavefront 0)", 14: "closing barrier (+ tail of the outputs)"}
 phys = float(med[:11].sum())
 print(json.dumps({"policy": policy, "envs": N, "cycles_per_step": {"policy tile (wavefront 0)": round(float(med[13])), "physics step (all its phases)": round(phys),
-                  "closing barrier": round(float(med[14]))}, "total": round(float(med[13] + phys + med[14]))}))
+                  "closing barrier": round(float(med[14]))}, "total": round(float(med[13] + phys + med[14])),
+                  "policy_wavefronts_cycles_per_step": {f"P{w}": [round(float(med[16 * (w + 1) + k])) for k in range(10)] for w in range(3)},
+                  "policy_buckets": ["wait physics + obs tile", "barrier", "layer 1", "barrier", "layer 2", "barrier", "layer 3", "barrier", "head + sampling", "barrier"]}))
