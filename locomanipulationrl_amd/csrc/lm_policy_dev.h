@@ -245,14 +245,32 @@ struct ResLayer {
 #pragma unroll
     for (int st = 0; st < IN_STEPS; st++) bv[st] = sIn[mlp_krow<NATURAL>(st, g) * MLP_IN_STRIDE(NATURAL) + n];
     __builtin_amdgcn_sched_barrier(0);
+    // The resident weights sit in accumulation registers; an MFMA issued right behind the v_accvgpr_read that fetches its A operand stalls
+    // on it (60 cycles per MFMA instead of 34, tools/microbench/mfma_chains.hip "valu-fed").  So the weights of GRP k-steps of all the
+    // wavefront's output blocks are moved to ordinary registers in one batch, then their MFMAs issue with nothing in between.
+    constexpr int GRP = (CNT > 3) ? ((IN_STEPS % 8 == 0) ? 8 : 11) : ((IN_STEPS % 16 == 0) ? 16 : ((IN_STEPS % 11 == 0) ? 11 : 8));      // at most 48 staged weights
+    static_assert(IN_STEPS % GRP == 0, "k-step groups");
+    f32x4 acc[CNT > 0 ? CNT : 1];
+#pragma unroll
+    for (int j = 0; j < CNT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < IN_STEPS; s0 += GRP) {
+      float ws[CNT > 0 ? CNT : 1][GRP];
+#pragma unroll
+      for (int j = 0; j < CNT; j++)
+#pragma unroll
+        for (int i = 0; i < GRP; i++) { ws[j][i] = w[j * IN_STEPS + s0 + i]; if (CNT <= 3) asm volatile("" : "+v"(ws[j][i])); }      // (layer 1, 5-6 blocks of 16 k-steps: staging costs more registers than it saves stalls)
+      if (CNT <= 3) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GRP; i++)
+#pragma unroll
+        for (int j = 0; j < CNT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j][i], bv[s0 + i], acc[j], 0, 0, 0);
+      if (CNT <= 3) __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int j = 0; j < CNT; j++) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int st = 0; st < IN_STEPS; st++)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j * IN_STEPS + st], bv[st], acc, 0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const float v = acc[k] + br[4 * j + k]; sOut[(16 * O::mb(j) + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
+      for (int k = 0; k < 4; k++) { const float v = acc[j][k] + br[4 * j + k]; sOut[(16 * O::mb(j) + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
     }
   }
 };
