@@ -1064,6 +1064,8 @@ struct StepArgs {
   int nsub;         // < 0: params.substeps, otherwise that many sub-steps (0 = read-back + task layer only)
   int64_t* drc;     // domain-randomisation counters [LM_DR_CNT_ROWS][N] (k_step_dr only)
   float* dr_phys;   // [LM_DR_PHYS_ROWS][N] attributes sampled for this step (k_step_dr only)
+  int kind[2];      // variant * 2 + (mode == LM_MODE_MANI) of the two parameter blocks: the kernels pick their specialisation from the kernel
+                    // arguments, so the first loads of the step do not wait for a round trip to the parameter block
 };
 
 template <int MODE, int VAR, int DR, int DEFER = 0>
@@ -1295,9 +1297,10 @@ __global__ void __launch_bounds__(64) k_step(StepArgs A) {
   LM_STAMP(11); LM_STAMP(12);      // two stamps back to back: bucket 12 = the cost of a stamp
   const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
 #endif
-  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash); }
-  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash); }
-  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(A, P, sTab, sObs, sSt, sStash); }
+  const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
+  if (kind == 0) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else if (kind == 1) step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash);
+  else if (kind == 2) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else if (kind == 3) step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash);
+  else if (kind == 4) step_body<0, 2, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(A, P, sTab, sObs, sSt, sStash);
 #ifdef LM_STAMPS
   { const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime(), mt1_ = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { lm_stamp_lds[13] = mt1_ - mt0_; lm_stamp_lds[14] = rt1_ - rt0_; } }
@@ -1314,9 +1317,10 @@ __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
   __shared__ float4 sStash[STASH_SLOTS * 64];
   const int env0 = lm_block() * ENVS_PER_WAVE;
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
-  if (P->variant == 0) { if (P->mode == LM_MODE_LOCO) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash); }
-  else if (P->variant == 1) { if (P->mode == LM_MODE_LOCO) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash); }
-  else { if (P->mode == LM_MODE_LOCO) step_body<0, 2, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 1>(A, P, sTab, sObs, sSt, sStash); }
+  const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
+  if (kind == 0) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else if (kind == 1) step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash);
+  else if (kind == 2) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else if (kind == 3) step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash);
+  else if (kind == 4) step_body<0, 2, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 1>(A, P, sTab, sObs, sSt, sStash);
 }
 
 
@@ -1837,6 +1841,7 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   A.W.stats = (char*)h->d_stats; A.W.extras = h->d_extras; A.W.out_extras = nullptr; A.W.split_block = h->split / ENVS_PER_WAVE; A.W.acc_rows = h->acc_rows;
   A.W.out_obs = out_obs; A.W.out_states = out_states; A.W.out_rew = out_rew; A.W.out_resets = out_resets;
   A.N = h->N; A.split = h->split; A.seed = h->seed; A.skip_reset = 0; A.nsub = -1; A.drc = h->d_drc; A.dr_phys = h->d_dr_phys;
+  for (int t = 0; t < 2; t++) A.kind[t] = h->h_params[t].variant * 2 + (h->h_params[t].mode == LM_MODE_MANI ? 1 : 0);
   return A;
 }
 
