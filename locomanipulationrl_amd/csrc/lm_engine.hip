@@ -310,9 +310,12 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // The Delassus operator is  W_ij = delta_ij D_i + T_i^T Phi T_j  (arrowhead structure of the hub + limbs system).
 // Each lane keeps the current contact-space velocity c (3) of ITS contact, its own full 3x3 block, and the 3x3
 // cross blocks X_K = T_i^T B_K towards the other three contacts; lanes take turns, the lane whose turn it is
-// relaxes its three rows, then its three impulse increments are quad-broadcast and every other lane updates c
-// with 9 FMAs.  Identical arithmetic (up to rounding) to row-wise PGS on the dense 12x12 system of the oracle.
-struct PgsData { float Wf[6]; float rW[3]; f2 Xp[4][3]; float Xs[4][3]; };      // this contact's 3x3 block towards contact K (K == own limb: the own block), by columns s: Xp[K][s] = (X[0][s] | X[1][s]), Xs[K][s] = X[2][s]
+// relaxes its normal row and then its two friction rows together (one packed update: both see the state the normal row left,
+// their mutual coupling enters at the contact's next turn), then its three impulse increments are quad-broadcast and every
+// lane updates c.  Identical arithmetic (up to rounding) to the oracle's sweep over the dense 12x12 system.
+// Row layout: row 0 (normal) in plain registers, rows 1 | 2 (friction) as one packed pair.
+struct PgsData { float W00, rW0; f2 W0t, nrWt; float X0[4][3]; f2 X12[4][3]; };   // own block: W00, (W01 | W02), minus reciprocal diagonal (-1/W11 | -1/W22);
+                                                                                   // block towards contact K (K == own limb: the own block) by columns s: X0[K][s] = X[0][s], X12[K][s] = (X[1][s] | X[2][s])
 
 // ---- "four 6-vectors at once" layout of the pass linear algebra.  Component i of the vectors (v0, v1, v2, v3) is an R4: p = (v0[i] | v1[i]),
 // q = (v2[i] | v3[i]), so that an operation applied to all four is two packed-fp32 instructions and any single entry is a free half-register
@@ -363,49 +366,46 @@ LM_DEV void chol6_solve4(const Chol6& C, R4 x[6]) {
   }
 }
 
-// 3x3 block of this lane's contact rows T_i against the B vectors of contact K:  X[3 r + s] = T_i,r . B_K,s  (K == own limb: the own block)
+// 3x3 block of this lane's contact rows T_i against the B vectors of contact K:  X[r][s] = T_i,r . B_K,s  (K == own limb: the own block)
 template <int K>
-LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float Wf[6], f2 Xp[3], float Xs[3]) {
-  f2 a0 = sp2(0.f), a1 = sp2(0.f), a2 = sp2(0.f); float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float Wf[6], float X0[3], f2 X12[3]) {
+  float a00 = 0.f; f2 a0t = sp2(0.f), c0 = sp2(0.f), c1 = sp2(0.f), c2 = sp2(0.f);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const float k0 = quad_bcast<K>(X[i].p.y); const f2 k12 = mk2(quad_bcast<K>(X[i].q.x), quad_bcast<K>(X[i].q.y));
-    const float t0 = T[i].p.y, t1 = T[i].q.x, t2 = T[i].q.y;
-    b0 = fmaf(t0, k0, b0); b1 = fmaf(t1, k0, b1); b2 = fmaf(t2, k0, b2);
-    a0 = fma_(sp2(t0), k12, a0); a1 = fma_(sp2(t1), k12, a1); a2 = fma_(sp2(t2), k12, a2);
+    const float t0 = T[i].p.y; const f2 t12 = T[i].q;
+    a00 = fmaf(t0, k0, a00); a0t = fma_(sp2(t0), k12, a0t);                                   // row 0: column 0, columns (1 | 2)
+    c0 = fma_(t12, sp2(k0), c0); c1 = fma_(t12, sp2(k12.x), c1); c2 = fma_(t12, sp2(k12.y), c2);      // rows (1 | 2): columns 0, 1, 2
   }
   const bool own = (limb == K);
-  // rows r = 0, 1, 2 of the block; column s = 0 from the b's, columns 1 and 2 from the a's
-  Xp[0] = mk2(own ? Wf[0] : b0, own ? Wf[1] : b1);     Xs[0] = own ? Wf[2] : b2;
-  Xp[1] = mk2(own ? Wf[1] : a0.x, own ? Wf[3] : a1.x); Xs[1] = own ? Wf[4] : a2.x;
-  Xp[2] = mk2(own ? Wf[2] : a0.y, own ? Wf[4] : a1.y); Xs[2] = own ? Wf[5] : a2.y;
+  X0[0] = own ? Wf[0] : a00; X0[1] = own ? Wf[1] : a0t.x; X0[2] = own ? Wf[2] : a0t.y;
+  X12[0] = mk2(own ? Wf[1] : c0.x, own ? Wf[2] : c0.y);
+  X12[1] = mk2(own ? Wf[3] : c1.x, own ? Wf[4] : c1.y);
+  X12[2] = mk2(own ? Wf[4] : c2.x, own ? Wf[5] : c2.y);
 }
 
-// One Gauss-Seidel turn: contact K relaxes its rows n, t1, t2 in sequence (each row sees the rows before it through the two
-// temporaries t1, t2), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies
-// c += X[K] * d.  Lanes whose turn it is not run the same instructions on their own (discarded) candidates; only `lam` is guarded.
+// One Gauss-Seidel turn: contact K relaxes its normal row, then its two friction rows as a pair (both from the state the normal row
+// left), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies c += X[K] * d.  Lanes whose
+// turn it is not run the same instructions on their own (discarded) candidates; only `lam` is guarded.
 template <int K>
-LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float lam[3], f2& c01, float& c2) {
+LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float& lam0, f2& lam12, float& c0, f2& c12) {
   const bool mine = (limb == K);
-  const float ln = fmaxf(0.0f, fmaf(-c01.x, G.rW[0], lam[0]));
-  const float d0 = ln - lam[0];
+  const float ln = fmaxf(0.0f, fmaf(-c0, G.rW0, lam0));
+  const float d0 = ln - lam0;
   const float lim = mu * ln;
-  const float t1 = fmaf(G.Wf[1], d0, c01.y);
-  const float l1 = __builtin_amdgcn_fmed3f(fmaf(-t1, G.rW[1], lam[1]), -lim, lim);
-  const float d1 = l1 - lam[1];
-  const float t2 = fmaf(G.Wf[4], d1, fmaf(G.Wf[2], d0, c2));
-  const float l2 = __builtin_amdgcn_fmed3f(fmaf(-t2, G.rW[2], lam[2]), -lim, lim);
-  const float d2 = l2 - lam[2];
-  lam[0] = mine ? ln : lam[0]; lam[1] = mine ? l1 : lam[1]; lam[2] = mine ? l2 : lam[2];
-  const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d1), b2 = quad_bcast<K>(d2);
-  c01 = fma_(G.Xp[K][0], sp2(b0), fma_(G.Xp[K][1], sp2(b1), fma_(G.Xp[K][2], sp2(b2), c01)));
-  c2 = fmaf(G.Xs[K][0], b0, fmaf(G.Xs[K][1], b1, fmaf(G.Xs[K][2], b2, c2)));
+  const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
+  const f2 l12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lim, lim), __builtin_amdgcn_fmed3f(u12.y, -lim, lim));
+  const f2 d12 = l12 - lam12;
+  lam0 = mine ? ln : lam0; lam12 = mk2(mine ? l12.x : lam12.x, mine ? l12.y : lam12.y);
+  const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d12.x), b2 = quad_bcast<K>(d12.y);
+  c0 = fmaf(G.X0[K][0], b0, fmaf(G.X0[K][1], b1, fmaf(G.X0[K][2], b2, c0)));
+  c12 = fma_(G.X12[K][0], sp2(b0), fma_(G.X12[K][1], sp2(b1), fma_(G.X12[K][2], sp2(b2), c12)));
 }
 
 // T[i].p.y, T[i].q = this lane's three contact rows (hub / plate wrench per unit impulse); X[i].p.y, X[i].q = B = Phi T
 LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3], const float Wl[6],
                       const R4 T[6], const R4 X[6], float lam[3], float w[6]) {
-  PgsData G;
+  PgsData G; float Wf[6];
   // full own block = limb-local part + hub/plate part T_r^T Phi T_s
   {
     f2 a0 = sp2(0.f), a1 = sp2(0.f), a2 = sp2(0.f); float b0 = 0.f;
@@ -414,32 +414,32 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
       b0 = fmaf(T[i].p.y, X[i].p.y, b0);
       a0 = fma_(sp2(T[i].p.y), X[i].q, a0); a1 = fma_(sp2(T[i].q.x), X[i].q, a1); a2 = fma_(sp2(T[i].q.y), X[i].q, a2);
     }
-    G.Wf[0] = Wl[0] + b0; G.Wf[1] = Wl[1] + a0.x; G.Wf[2] = Wl[2] + a0.y;
-    G.Wf[3] = Wl[3] + a1.x; G.Wf[4] = Wl[4] + a1.y; G.Wf[5] = Wl[5] + a2.y;
+    Wf[0] = Wl[0] + b0; Wf[1] = Wl[1] + a0.x; Wf[2] = Wl[2] + a0.y;
+    Wf[3] = Wl[3] + a1.x; Wf[4] = Wl[4] + a1.y; Wf[5] = Wl[5] + a2.y;
   }
-  G.rW[0] = 1.0f / G.Wf[0]; G.rW[1] = 1.0f / G.Wf[3]; G.rW[2] = 1.0f / G.Wf[5];
-  pgs_cross_blocks<0>(limb, T, X, G.Wf, G.Xp[0], G.Xs[0]); pgs_cross_blocks<1>(limb, T, X, G.Wf, G.Xp[1], G.Xs[1]);
-  pgs_cross_blocks<2>(limb, T, X, G.Wf, G.Xp[2], G.Xs[2]); pgs_cross_blocks<3>(limb, T, X, G.Wf, G.Xp[3], G.Xs[3]);
-  lam[0] = lam[1] = lam[2] = 0.f;
-  f2 c01 = mk2(vf[0] + bn, vf[1]); float c2 = vf[2];
+  G.W00 = Wf[0]; G.rW0 = 1.0f / Wf[0]; G.W0t = mk2(Wf[1], Wf[2]); G.nrWt = mk2(-1.0f / Wf[3], -1.0f / Wf[5]);
+  pgs_cross_blocks<0>(limb, T, X, Wf, G.X0[0], G.X12[0]); pgs_cross_blocks<1>(limb, T, X, Wf, G.X0[1], G.X12[1]);
+  pgs_cross_blocks<2>(limb, T, X, Wf, G.X0[2], G.X12[2]); pgs_cross_blocks<3>(limb, T, X, Wf, G.X0[3], G.X12[3]);
+  float lam0 = 0.f; f2 lam12 = sp2(0.f);
+  float c0 = vf[0] + bn; f2 c12 = mk2(vf[1], vf[2]);
   // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
   // ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
   for (int it = 0; it < iters; it += 2) {
-    pgs_turn<0>(limb, mu, G, lam, c01, c2);
-    pgs_turn<1>(limb, mu, G, lam, c01, c2);
-    pgs_turn<2>(limb, mu, G, lam, c01, c2);
-    pgs_turn<3>(limb, mu, G, lam, c01, c2);
+    pgs_turn<0>(limb, mu, G, lam0, lam12, c0, c12);
+    pgs_turn<1>(limb, mu, G, lam0, lam12, c0, c12);
+    pgs_turn<2>(limb, mu, G, lam0, lam12, c0, c12);
+    pgs_turn<3>(limb, mu, G, lam0, lam12, c0, c12);
     if (it + 1 < iters) {
-      pgs_turn<3>(limb, mu, G, lam, c01, c2);
-      pgs_turn<2>(limb, mu, G, lam, c01, c2);
-      pgs_turn<1>(limb, mu, G, lam, c01, c2);
-      pgs_turn<0>(limb, mu, G, lam, c01, c2);
+      pgs_turn<3>(limb, mu, G, lam0, lam12, c0, c12);
+      pgs_turn<2>(limb, mu, G, lam0, lam12, c0, c12);
+      pgs_turn<1>(limb, mu, G, lam0, lam12, c0, c12);
+      pgs_turn<0>(limb, mu, G, lam0, lam12, c0, c12);
     }
   }
+  lam[0] = lam0; lam[1] = lam12.x; lam[2] = lam12.y;
   // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
-  const f2 l12 = mk2(lam[1], lam[2]);
 #pragma unroll
-  for (int i = 0; i < 6; i++) { const f2 t = l12 * X[i].q; w[i] = quad_sum(fmaf(lam[0], X[i].p.y, t.x + t.y)); }
+  for (int i = 0; i < 6; i++) { const f2 t = lam12 * X[i].q; w[i] = quad_sum(fmaf(lam0, X[i].p.y, t.x + t.y)); }
 }
 
 // free rigid body carried as (position, quaternion, body-coordinate spatial velocity about its origin)

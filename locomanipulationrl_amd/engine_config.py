@@ -13,13 +13,18 @@ Values and where they come from in the reference:
 Contact parameters (mu, baumgarte, max_depen_vel, pgs_iters) belong to THIS engine's
 contact model; the reference delegates contact to PhysX (TGS, 16+2
 iterations, contact_offset 0.005, max depenetration velocity 100 -- YAML :41-50) whose
-algorithm is not reproducible here.  Two values were moved in round 2 on the evidence of the
-reference's recorded PhysX joint trajectories (tests/golden/npy_traj.npz):
-  tip_radius 0.005: the foot is the 5 mm hemisphere that ends the long distal link's collision mesh
-  tau_max = max effort / dt: the simulator the reference ran on (Isaac Sim 2022.2 / PhysX 5.1) reads an articulation drive's
-      maxForce as an IMPULSE limit per physics step unless PxArticulationFlag::eDRIVE_LIMITS_ARE_FORCES is raised, so
-      `set_max_efforts(1.5)` (robot.py:347-355) bounds the drive at 1.5 N m s per 0.0083 s step = 180.7 N m, i.e. not at all
-      in practice; with a 1.5 N m torque clamp the recorded joint motions are infeasible for this robot (section 2's table).
+algorithm is not reproducible here.  Values chosen on the evidence of the reference's recorded PhysX joint
+trajectories (tests/golden/npy_traj.npz; tests/npy_replay_evidence.py prints the tables):
+  tip_radius 0.005 (round 2): the foot is the 5 mm hemisphere that ends the long distal link's collision mesh
+  tau_max = max_effort / dt (round 2; PARITY UNPINNED): the recorded joints follow their velocity commands through full-speed
+      reversals within one control period, which a 1.5 N m torque clamp on this 2.26 kg robot cannot do in this engine (section 2.1's
+      negative control); the drive limit is therefore read as PhysX's per-step IMPULSE limit (1.5 N m s per 0.0083 s step = 180.7 N m,
+      never binding).  Whether the reference's Isaac build raised PxArticulationFlag::eDRIVE_LIMITS_ARE_FORCES cannot be checked here,
+      and row 0 of the same recordings (the joints give way by 3e-3 ... 1.25e-2 rad while the scene settles) is reproduced only by a
+      drive that yields at about 1.5 N m - no single reading fits both, see DESIGN.md 2.2.  `drive_limits_are_impulses=False` selects
+      the torque reading; bench.py reports the headline under both.
+  pgs_iters 32 on the ground, 8 on the plate (round 3): the replay's orientation outcomes are those of the converged contact solve
+      from 28 Gauss-Seidel sweeps on (identical for 28 ... 128) on the ground; on the plate they are identical from 8 to 256 sweeps.
 """
 from __future__ import annotations
 
@@ -27,6 +32,7 @@ from dataclasses import dataclass, field, replace
 from typing import List
 
 
+PGS_ITERS_GROUND, PGS_ITERS_PLATE = 32, 8
 MODE_LOCO = 0    # free base on a ground plane
 MODE_MANI = 1    # fixed (inverted) base + free plate
 DRIVE_VELOCITY, DRIVE_POSITION, DRIVE_EFFORT = 0, 1, 2
@@ -64,10 +70,12 @@ class EngineParams:
     # ---- physics
     dt: float = 0.0083
     substeps: int = 4
-    pgs_iters: int = 8
+    pgs_iters: int = -1                 # contact sweeps per solve; -1 = by contact surface: 32 on the ground, 8 on the plate (see above)
     gravity: float = 9.81
     kd: float = 100.0
-    tau_max: float = 1.5 / 0.0083       # velocity-drive tasks: max effort 1.5 read as an impulse limit per step (see above); PD families: 1.5 N m
+    max_effort: float = 1.5             # ArticulationView.set_max_efforts (robot.py:347-355); host-side only, tau_max is what the engine reads
+    drive_limits_are_impulses: bool = True
+    tau_max: float = -1.0               # -1 = from max_effort: max_effort / dt (impulse limit per step, see above) or max_effort (torque clamp)
     act_scale: float = 3.0
     mu: float = 1.0
     tip_radius: float = 0.005
@@ -147,6 +155,12 @@ class EngineParams:
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 
+    def __post_init__(self):
+        if self.tau_max < 0:
+            self.tau_max = self.max_effort / self.dt if (self.drive_limits_are_impulses and self.dt > 0) else self.max_effort
+        if self.pgs_iters < 0:
+            self.pgs_iters = PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE
+
     @property
     def ctrl_dt(self) -> float:
         return self.dt * self.substeps
@@ -154,13 +168,13 @@ class EngineParams:
 
 def loco_params(**kw) -> EngineParams:
     """Horizontal locomotion task (QuadrupedPoseControl)."""
-    return replace(EngineParams(), **kw)
+    return EngineParams(**kw)
 
 
 def mani_params(**kw) -> EngineParams:
     """Horizontal manipulation task (QuadrupedManipulatePlate): fixed inverted base at the origin,
     plate dropped from z = 0.14 (quadruped_manipulate_plate.py:91-94,150-151)."""
-    return replace(EngineParams(mode=MODE_MANI), **kw)
+    return EngineParams(**{**dict(mode=MODE_MANI), **kw})
 
 
 _CLASS_DEFAULT_Q = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]      # robot/quadruped_robot.py:45-52
@@ -179,12 +193,12 @@ def _cc(**kw):
 
 def loco_cc_params(**kw) -> EngineParams:
     """QuadrupedPoseControlCustomController: class-default pose, base at z 0.18, fixed goal yaw 1.57 (:67-78)."""
-    return replace(EngineParams(), **_cc(**{**dict(init_base_pos=[0.0, 0.0, 0.18], goal_lo=[0.0, 0.0, 1.57], goal_hi=[0.0, 0.0, 1.57]), **kw}))
+    return EngineParams(**_cc(**{**dict(init_base_pos=[0.0, 0.0, 0.18], goal_lo=[0.0, 0.0, 1.57], goal_hi=[0.0, 0.0, 1.57]), **kw}))
 
 
 def mani_cc_params(**kw) -> EngineParams:
     """QuadrupedManipulatePlateCustomController: plate dropped from z 0.18 onto the inverted fixed robot."""
-    return replace(EngineParams(mode=MODE_MANI), **_cc(**{**dict(init_plate_pos=[0.0, 0.0, 0.18], cc_update_last_tgt=0), **kw}))
+    return EngineParams(**_cc(**{**dict(mode=MODE_MANI, init_plate_pos=[0.0, 0.0, 0.18], cc_update_last_tgt=0), **kw}))
 
 
 _PC_INIT_SE = [-1.57, 1.57, 1.57, -1.57, -1.57, 1.05, 1.57, 1.05, 1.57, 1.05, -1.57, 1.05]
@@ -205,10 +219,10 @@ def _pc(**kw):
 
 def loco_pc_params(**kw) -> EngineParams:
     """QuadrupedPoseControlPositionControl."""
-    return replace(EngineParams(), **_pc(**kw))
+    return EngineParams(**_pc(**kw))
 
 
 def mani_pc_params(**kw) -> EngineParams:
     """QuadrupedManipulatePlatePositionControl: inverted fixed robot at z 0.3, plate dropped from z 0.44, 450-step episodes
     (quadruped_manipulate_plate_position_control.py:122-124,177; cfg/task/QuadrupedManipulatePlatePositionControl.yaml:18)."""
-    return replace(EngineParams(mode=MODE_MANI), **_pc(**{**dict(fixed_base_pos=[0.0, 0.0, 0.3], init_plate_pos=[0.0, 0.0, 0.44], max_episode=450), **kw}))
+    return EngineParams(**_pc(**{**dict(mode=MODE_MANI, fixed_base_pos=[0.0, 0.0, 0.3], init_plate_pos=[0.0, 0.0, 0.44], max_episode=450), **kw}))

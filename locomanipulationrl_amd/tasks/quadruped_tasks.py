@@ -90,17 +90,17 @@ class _QuadrupedTask(RLTask):
         else:
             d1_pen = [[lo1, hi1]] * 4; d1_rst = [[rlo1, rhi1]] * 4
         g = sim.get("gravity", [0, 0, -9.81])
-        # Drive effort limit.  The reference calls ArticulationView.set_max_efforts(1.5) (robot.py:347-355) on Isaac Sim 2022.2 / PhysX 5.1,
-        # where an articulation drive's maxForce is an IMPULSE limit per physics step unless PxArticulationFlag::eDRIVE_LIMITS_ARE_FORCES
-        # is raised: 1.5 N m s per dt = 180.7 N m.  The reference's recorded PhysX joint trajectories confirm that the limit never binds
-        # (with a 1.5 N m clamp those motions are infeasible).  `sim.engine.drive_limits_are_impulses: False`
-        # restores the torque reading.  The PD-actuator tasks clamp their torque in Python (…custom_controller.py:289-307): a real 1.5 N m.
-        tau_lim = float(rd.torque_limits[0])
-        if bool(eng.get("drive_limits_are_impulses", True)):
-            tau_lim = tau_lim / float(sim["dt"])
+        # Drive effort limit: ArticulationView.set_max_efforts(1.5) (robot.py:347-355).  Read as PhysX's per-step impulse limit (max_effort / dt,
+        # never binding) by default - PARITY UNPINNED, engine_config.py and DESIGN.md 2.1 / 2.2 give the evidence for and against;
+        # `sim.engine.drive_limits_are_impulses: False` selects the 1.5 N m torque clamp.  The PD-actuator tasks clamp their torque in Python
+        # (…custom_controller.py:289-307): a real 1.5 N m either way.
+        mode = kw.get("mode", MODE_LOCO)
+        sweeps = eng.get("pgs_iters", {})          # contact sweeps per solve: {ground: 32, plate: 8}; a plain integer sets both
+        if isinstance(sweeps, dict):
+            sweeps = sweeps.get("ground" if mode == MODE_LOCO else "plate", -1)
         base = dict(
-            dt=float(sim["dt"]), substeps=int(self.control_frequency_inv), pgs_iters=int(eng.get("pgs_iters", 8)), gravity=float(-g[2]),
-            kd=float(rd.joint_kds[0]), tau_max=tau_lim, act_scale=float(rd.velocity_limits[0]), mu=mu, drive_mode=0,
+            dt=float(sim["dt"]), substeps=int(self.control_frequency_inv), pgs_iters=int(sweeps), gravity=float(-g[2]),
+            kd=float(rd.joint_kds[0]), max_effort=float(rd.torque_limits[0]), drive_limits_are_impulses=bool(eng.get("drive_limits_are_impulses", True)), act_scale=float(rd.velocity_limits[0]), mu=mu, drive_mode=0,
             tip_radius=float(eng.get("tip_radius", 0.005)), baumgarte=float(eng.get("baumgarte", 0.2)),
             max_depen_vel=float(eng.get("max_depenetration_velocity", 1.0)),
             max_joint_vel=float(eng.get("max_joint_velocity_deg", 450.0)) * 3.141592653589793 / 180.0,

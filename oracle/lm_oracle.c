@@ -367,8 +367,10 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
       const int i=(it&1)?3-ii:ii;      /* sweeps alternate direction: no limb is systematically relaxed first */
       int r=3*i; real v=vf[r]+bn[i]; for (int c=0;c<12;c++) v+=W[r][c]*lam[c];
       real ln=lam[r]-v/W[r][r]; if (ln<0) ln=0; lam[r]=ln;
-      for (int k=1;k<3;k++) { int rr=r+k; real vt=vf[rr]; for (int c=0;c<12;c++) vt+=W[rr][c]*lam[c];
-        real lt=lam[rr]-vt/W[rr][rr]; real lim=mu*lam[r]; if (lt>lim) lt=lim; if (lt<-lim) lt=-lim; lam[rr]=lt; }
+      /* the two friction rows of a contact relax together, both from the state the normal row left (one packed update in the kernel);
+         their mutual coupling W[t1][t2] enters at the contact's next turn */
+      real vt[2]; for (int k=1;k<3;k++) { int rr=r+k; vt[k-1]=vf[rr]; for (int c=0;c<12;c++) vt[k-1]+=W[rr][c]*lam[c]; }
+      for (int k=1;k<3;k++) { int rr=r+k; real lt=lam[rr]-vt[k-1]/W[rr][rr]; real lim=mu*lam[r]; if (lt>lim) lt=lim; if (lt<-lim) lt=-lim; lam[rr]=lt; }
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
     if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];

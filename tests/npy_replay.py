@@ -56,27 +56,40 @@ def rot_dist(obs_row):
     return 2.0 * np.arcsin(min(float(np.linalg.norm(obs_row[7:10])), 1.0))
 
 
-def replay(rec, step, servo=False):
-    """step(action (12,)) -> (q (12,), obs (64,), reset flag, goal_reset flag) advances one control step; the first call gets the zero
-    action of VecEnvRLGames.reset().  servo=True steers the joints back onto the recording every step (actions still clipped to +-1)."""
+def replay(rec, step, servo=False, until_done=False):
+    """step(action (12,)) -> (q (12,), obs (64,), reset flag, goal_reset flag, reward) advances one control step; the first call gets the
+    zero action of VecEnvRLGames.reset().  servo=True steers the joints back onto the recording every step (actions still clipped to +-1).
+    The replay stops on the engine's own reset flag or after the recording's last row (until_done: holds the last action's successor at
+    zero and keeps stepping up to 8 more rows, to see a success streak that started late complete)."""
     T = rec.shape[0]
-    q, obs, rst, _ = step(np.zeros(12))
-    out = dict(T=T, row0_err=float(np.abs(q - rec[0]).max()), rows=[q.copy()], rd=[rot_dist(obs)], done_at=None, goal=0)
+    q, obs, rst, _, rew = step(np.zeros(12))
+    out = dict(T=T, row0_err=float(np.abs(q - rec[0]).max()), row0=q.copy(), rows=[q.copy()], rd=[rot_dist(obs)], rew=[rew], done_at=None, goal=0)
     acts = recovered_actions(rec)
     derr = []
     for t in range(T - 1):
         a = np.clip((rec[t + 1] - q) / FULL, -1, 1) if servo else acts[t]
         q0 = q
-        q, obs, rst, goal = step(a)
-        out["rows"].append(q.copy()); out["rd"].append(rot_dist(obs)); derr.append((q - q0) - (rec[t + 1] - rec[t]))
+        q, obs, rst, goal, rew = step(a)
+        out["rows"].append(q.copy()); out["rd"].append(rot_dist(obs)); out["rew"].append(rew); derr.append((q - q0) - (rec[t + 1] - rec[t]))
         if rst:
             out["done_at"], out["goal"] = t + 1, int(goal)
             break
+    out["rd_rec"] = np.array(out["rd"])                      # rot_dist over the recorded rows only
+    if until_done and out["done_at"] is None:
+        for k in range(8):                                   # the recording is over: hold still (zero velocity targets) and let a late streak complete
+            q, obs, rst, goal, rew = step(np.zeros(12))
+            out["rd"].append(rot_dist(obs)); out["rew"].append(rew)
+            if rst:
+                out["done_at"], out["goal"] = T + k, int(goal)
+                break
     rows = np.array(out["rows"]); derr = np.array(derr); n = len(rows)
-    out.update(rows=rows, rd=np.array(out["rd"]), tracked=float((np.abs(derr) < 1e-3).mean()), qerr=float(np.abs(rows - rec[:n]).max()),
+    out.update(rows=rows, rd=np.array(out["rd"]), rew=np.array(out["rew"]), tracked=float((np.abs(derr) < 1e-3).mean()), qerr=float(np.abs(rows - rec[:n]).max()),
                early=float(np.abs(derr[:4]).mean() / FULL), succ_row=T - 17)
-    first = np.nonzero(out["rd"] <= 0.15)[0]
+    first = np.nonzero(out["rd_rec"] <= 0.15)[0]
     out["first_succ"] = int(first[0]) if len(first) else None
+    # rows of PhysX's success window [T - 17, T - 1] on which this replay is inside the 0.15 rad window too (rows it did not reach count as outside)
+    win = out["rd_rec"][T - 17:T]
+    out["in_window"] = int((win <= 0.15).sum())
     return out
 
 
@@ -87,10 +100,10 @@ def oracle_stepper(robot_model, ep, precision="f64"):
 
     def step(a):
         obs, st, rew, terms = o.step(phys, task, cnt, np.asarray(a, dtype=np.float64)[None], seed=0)
-        return phys[0, 13:25].astype(np.float64).copy(), obs[0].astype(np.float64), int(cnt[0, 3]), int(cnt[0, 2])
+        return phys[0, 13:25].astype(np.float64).copy(), obs[0].astype(np.float64), int(cnt[0, 3]), int(cnt[0, 2]), float(rew[0])
     return step
 
 
 def summary_line(name, r):
     return (f"{name:30s} T-1={r['T'] - 1:3d} row0={r['row0_err']:.4f} tracked={r['tracked']:.3f} qerr={r['qerr']:.3f} early={r['early']:.4f} "
-            f"done_at={r['done_at']}{'G' if r['goal'] else ''} first<=0.15:{r['first_succ']} (PhysX {r['succ_row']}) min rd={r['rd'].min():.3f} last rd={r['rd'][-1]:.3f}")
+            f"done_at={r['done_at']}{'G' if r['goal'] else ''} first<=0.15:{r['first_succ']} (PhysX {r['succ_row']}) min rd={r['rd_rec'].min():.3f} last rd={r['rd_rec'][-1]:.3f} in-window {r['in_window']}/17")
