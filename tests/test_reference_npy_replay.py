@@ -1,20 +1,30 @@
 """Row a7 against the reference's own PhysX data: open-loop replay of the 11 distinct recorded joint trajectories through the CPU oracle
-(here) and the HIP engine (-m gpu).  See tests/npy_replay.py for what the recordings are and DESIGN.md section 2 for the per-file table
-and for how the two spec parameters this test pins (drive limit read as an impulse, 5 mm foot hemisphere) were chosen on this evidence.
+(here) and the HIP engine (-m gpu).  See tests/npy_replay.py for what the recordings are, DESIGN.md section 2.1 for the per-file tables
+and for how the parameters this test pins were chosen on this evidence, and section 2.2 for row 0.
 
-Tolerances (the contract):
-  row 0 (one control period after reset, zero action)      joints within 5e-3 rad (loco) / 1.3e-2 rad (mani) of the recording
-  every file, open loop                                     >= 95 % of the joint-steps reproduce the recorded displacement to 1e-3 rad;
-                                                            joint positions stay within 0.05 rad of the recording over the whole episode
-                                                            (T = 23 ... 104 steps, no re-synchronisation)
-  first 4 steps (states still synchronised)                 mean |displacement error| <= 1 % of a full-scale step
-  `test` (the one file that ends in a fall)                 this engine terminates on the recorded last row
-  goal-known files (7 x mlp_*)                              rot_dist falls from >= 0.75 to <= 0.26 in every file, reaches the success window
-                                                            (<= 0.15) in at least 4 of 7, within 6 rows of PhysX where it does; no file terminates
-                                                            before PhysX did, except by the knee test within 3 rows of it
-  with the pre-round-2 reading (1.5 N m torque clamp)       the same replay tracks < 80 % of the joint-steps: the negative control
-The long-horizon orientation outcome is chaotic (a walking gait on four frictional point feet): which files hold the goal to the last row
-changes with any perturbation of the contact model, so only counts are asserted.
+What each group of assertions does and does not prove (the contract):
+
+  DRIVE-LIMIT CHECKS (joint level).  The replayed actions are DEFINED from the recording, a_t = clip(dq_rec / 0.0996), so any drive
+      strong enough to follow its command reproduces the joint rows by construction: >= 95 % of the joint-steps to 1e-3 rad, joints within
+      0.05 rad over whole episodes, mean early error <= 1 % of a full-scale step.  These pin ONE thing - the drive limit does not bind in
+      the reference - and say nothing about gravity, contact or inertia (with gravity or friction switched off they are met even better;
+      `test_joint_level_checks_are_a_drive_limit_test` keeps that on record).  Their negative control is the 1.5 N m torque clamp.
+  ORIENTATION / TERMINATION CHECKS (the physics).  The base pose is not recorded; it is pinned through what the task computed from it:
+      PhysX's rot_dist entered the 0.15 rad success window on row T - 17 of each of the seven goal-known episodes and `test` ended in a
+      fall on its last row.  Asserted PER KIND: locomotion >= 3 of 4 files enter the window, manipulation 3 of 3, each within 6 rows of
+      PhysX; every file gets from >= 0.75 rad to <= 0.26 rad; no file terminates before PhysX did except by the knee test within 3 rows of
+      PhysX's entry; `test` terminates on its recorded last row.
+      NEGATIVE CONTROLS THAT MUST FAIL these checks: gravity 0, friction 0, one Gauss-Seidel sweep, a 20 mm foot, the 1.5 N m clamp.
+  EPISODE REWARD (north star: "joint states and episode reward").  PhysX's episode is 17 rows inside the window (rot reward
+      0.5 / (rot_dist + 0.1) >= 2.0 each, quadruped_pose_control.py:428-462) and the 600 bonus on the last row.  The replay, held still after
+      the recording's last row for at most one streak length, must end in success and collect a return inside the bracket PhysX's episode
+      implies, for >= 2 of 4 locomotion and >= 2 of 3 manipulation files (the bonus is 94 % of the return: missing it is a 94 % error).
+  ROW 0 (one control period after reset, zero action).  PhysX's joints give way by 3e-3 ... 1.25e-2 rad (identical in every file); this
+      engine's by 1e-4 ... 3e-4 in the SAME direction on every joint.  The direction is asserted (a frozen robot fails it); the magnitude
+      is a documented residual (reproduced only by a drive that yields at ~1.5 N m, which the later rows rule out), bounded
+      here by the observed 4.2e-3 / 1.27e-2 so that it cannot grow unnoticed.
+The long-horizon outcome of a walking gait on four frictional point feet is chaotic: which individual files hold the goal changes with
+any perturbation of the contact model, so counts are asserted, never individual files.
 """
 import numpy as np
 import pytest
@@ -31,54 +41,133 @@ def test_fixture_is_the_reference_data(recordings):
     assert len(recordings) == 13 and all(a.shape[1] == 12 and 23 <= a.shape[0] <= 104 for a in recordings.values())
     assert np.array_equal(recordings["mlp_loco_from_scratch"], recordings["mlp_joint_loco_from_scratch"])      # the two duplicates
     assert np.array_equal(recordings["mlp_mani_from_scratch"], recordings["mlp_joint_mani_from_scratch"])
-    # the drive tracks its target within a control period: the 95th percentile of |dq| / 0.0332 s is the 3.00 rad/s action scale
+    # the drive tracks its target within a control period: the 95th percentile of |dq| / 0.0332 s is the 3.00 rad/s action scale, and the
+    # joints reverse from +full to -full speed inside ONE control period (e.g. 04roll_loco_from_mani joint 2, steps 10-12: +0.99, -0.99, +1.00)
     for k in R.FILES:
         v = np.abs(np.diff(recordings[k], axis=0)) / 0.0332
         if k != "04roll_mani_from_scratch":
             assert abs(np.percentile(v, 95) - 3.0) < 0.01, k
         assert v.max() < 3.75
+    d = np.diff(recordings["04roll_loco_from_mani"], axis=0)[:, 2] / R.FULL
+    assert d[10] > 0.98 and d[11] < -0.98 and d[12] > 0.98
+    # row 0 is deterministic and policy independent: identical in every file of a kind
+    for kind in ("loco", "mani"):
+        rows = np.array([recordings[k][0] for k in R.FILES if R.kind_of(k) == kind])
+        assert np.abs(rows - rows[0]).max() < 1e-6
+
+
+def run_all(robot_model, recordings, files=R.FILES, until_done=False, **kw):
+    return {name: R.replay(recordings[name], R.oracle_stepper(robot_model, R.cotrain_params(R.kind_of(name), **kw)), until_done=until_done) for name in files}
 
 
 @pytest.fixture(scope="module")
 def oracle_runs(robot_model, recordings):
-    out = {}
-    for name in R.FILES:
-        out[name] = R.replay(recordings[name], R.oracle_stepper(robot_model, R.cotrain_params(R.kind_of(name))))
-        print(R.summary_line(name, out[name]))
+    out = run_all(robot_model, recordings)
+    for name, r in out.items():
+        print(R.summary_line(name, r))
     return out
 
 
-def check_runs(runs):
+# ---------------------------------------------------------------------------------------------------------------- the checks
+def check_drive_limit(runs):
     for name, r in runs.items():
-        kind = R.kind_of(name)
-        assert r["row0_err"] < (5e-3 if kind == "loco" else 1.3e-2), (name, r["row0_err"])
         assert r["tracked"] >= 0.95, (name, r["tracked"])
         assert r["qerr"] <= 0.05, (name, r["qerr"])
         assert r["early"] <= 0.01, (name, r["early"])
+
+
+def reached_by_kind(runs):
+    out = {"loco": [0, 0], "mani": [0, 0]}
+    for name in R.GOAL_KNOWN:
+        k = R.kind_of(name); out[k][1] += 1; out[k][0] += runs[name]["first_succ"] is not None
+    return out
+
+
+def check_orientation(runs):
     t = runs["test"]
-    assert t["done_at"] == t["T"] - 1 and not t["goal"]
-    reached = 0
+    assert t["done_at"] == t["T"] - 1 and not t["goal"], ("test", t["done_at"])
     for name in R.GOAL_KNOWN:
         r = runs[name]
-        assert r["rd"][0] >= 0.75 and r["rd"].min() <= 0.26, (name, r["rd"][0], r["rd"].min())
+        assert r["rd"][0] >= 0.75 and r["rd_rec"].min() <= 0.26, (name, r["rd"][0], r["rd_rec"].min())
         if r["first_succ"] is not None:
-            reached += 1
             assert abs(r["first_succ"] - r["succ_row"]) <= 6, (name, r["first_succ"], r["succ_row"])
         if r["done_at"] is not None and r["done_at"] < r["T"] - 1:
             assert r["done_at"] >= r["succ_row"] - 3, (name, r["done_at"])
-    assert reached >= 4, reached
+    n = reached_by_kind(runs)
+    assert n["loco"][0] >= 3 and n["loco"][1] == 4, n
+    assert n["mani"][0] == 3 and n["mani"][1] == 3, n
 
 
-def test_reference_npy_replay_oracle(oracle_runs):
-    check_runs(oracle_runs)
+def orientation_ok(runs):
+    try:
+        check_orientation(runs)
+        return True
+    except AssertionError:
+        return False
 
 
-def test_torque_clamp_reading_is_refuted_by_the_recordings(robot_model, recordings):
-    """Negative control: with `set_max_efforts(1.5)` read as a 1.5 N m torque clamp (round 1's spec) the recorded joint motions cannot be
-    reproduced - joints are overpowered by the contact loads in the first synchronised steps already."""
+def check_row0(runs, recordings):
+    init = np.array(R.INIT_Q)
+    for kind, name, bound in (("loco", "mlp_joint_loco", 4.3e-3), ("mani", "mlp_joint_mani", 1.28e-2)):
+        d_eng = runs[name]["row0"] - init; d_ref = recordings[name][0] - init
+        moved = np.abs(d_eng) > 1e-5                                  # joints this engine moved at all (all 12 on the plate, 10 or 11 on the ground:
+        assert moved.sum() >= 10, (kind, d_eng)                      #  two hip joints barely load while the feet land)
+        assert (np.sign(d_eng[moved]) == np.sign(d_ref[moved])).all(), (kind, d_eng, d_ref)          # a frozen robot has no direction
+        assert runs[name]["row0_err"] < bound, (kind, runs[name]["row0_err"])      # the documented residual, not parity
+
+
+def episode_reward(r):
+    """This replay's return over PhysX's success window rows [T - 17, T - 1] plus the bonus if the episode ended in success, against the
+    bracket PhysX's episode implies: 17 rows of 0.5 / (rot_dist + 0.1) with rot_dist in [0, 0.15] (2.0 ... 5.0 each) minus at most 0.5 of
+    penalties per row, plus the 600 bonus."""
+    T = r["T"]
+    window = float(r["rew"][T - 17:T].sum()) if len(r["rew"]) >= T else float("nan")
+    bonus = 600.0 if (r["goal"] and r["done_at"] is not None and r["done_at"] >= T - 1) else 0.0
+    if bonus:
+        window -= 600.0 if r["done_at"] == T - 1 else 0.0            # the bonus is part of that row's reward when it falls inside the window
+    lo, hi = 17 * (2.0 - 0.5) + 600.0, 17 * 5.0 + 600.0
+    return dict(ret=window + bonus, lo=lo, hi=hi, ok=bool(lo <= window + bonus <= hi), bonus_row=r["done_at"] if bonus else None)
+
+
+def check_episode_reward(runs_until_done):
+    ok = {"loco": 0, "mani": 0}
+    for name in R.GOAL_KNOWN:
+        r = runs_until_done[name]; e = episode_reward(r)
+        print(f"{name:30s} return over PhysX's window rows + bonus {e['ret']:7.1f}  bracket [{e['lo']:.1f}, {e['hi']:.1f}]  bonus on row {e['bonus_row']} (PhysX {r['T'] - 1})")
+        if e["ok"]:
+            assert e["bonus_row"] - (r["T"] - 1) <= 17, name             # within one streak length of PhysX's last row
+            ok[R.kind_of(name)] += 1
+    assert ok["loco"] >= 2 and ok["mani"] >= 2, ok
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU oracle
+def test_reference_npy_replay_oracle(oracle_runs, recordings):
+    check_drive_limit(oracle_runs)
+    check_orientation(oracle_runs)
+    check_row0(oracle_runs, recordings)
+
+
+def test_episode_reward_of_the_replays(robot_model, recordings):
+    check_episode_reward(run_all(robot_model, recordings, files=R.GOAL_KNOWN, until_done=True))
+
+
+@pytest.mark.parametrize("label, kw", [("gravity 0", dict(gravity=0.0)), ("friction 0", dict(mu=0.0)), ("one Gauss-Seidel sweep", dict(pgs_iters=1)),
+                                       ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5))])
+def test_negative_controls_fail_the_orientation_checks(robot_model, recordings, label, kw):
+    """A broken simulator must not pass: each of these is rejected by the orientation / termination checks."""
+    runs = run_all(robot_model, recordings, files=R.GOAL_KNOWN + ["test"], **kw)
+    n = reached_by_kind(runs)
+    print(label, n, "test ends on", runs["test"]["done_at"])
+    assert not orientation_ok(runs), (label, n)
+
+
+def test_joint_level_checks_are_a_drive_limit_test(robot_model, recordings):
+    """On record: the joint-level statistics are met WITHOUT gravity and WITHOUT friction (the actions are defined from the recording), and
+    fail under the torque-clamp reading - they test the drive limit and nothing else."""
+    for kw in (dict(gravity=0.0), dict(mu=0.0)):
+        check_drive_limit(run_all(robot_model, recordings, **kw))
     tr, early = [], []
-    for name in R.FILES:
-        r = R.replay(recordings[name], R.oracle_stepper(robot_model, R.cotrain_params(R.kind_of(name), tau_max=1.5)))
+    for r in run_all(robot_model, recordings, tau_max=1.5).values():
         tr.append(r["tracked"]); early.append(r["early"])
     assert np.mean(tr) < 0.80 and np.mean(early) > 0.05, (np.mean(tr), np.mean(early))
 
@@ -89,6 +178,18 @@ def test_servo_replay_keeps_the_joints_on_the_recording(robot_model, recordings)
     for name in R.FILES:
         r = R.replay(recordings[name], R.oracle_stepper(robot_model, R.cotrain_params(R.kind_of(name))), servo=True)
         assert r["qerr"] <= 0.05 and np.abs(r["rows"] - recordings[name][:len(r["rows"])]).mean() < 2e-3, (name, r["qerr"])
+
+
+def test_sweep_count_is_in_the_converged_plateau(robot_model, recordings):
+    """The shipped sweep counts (32 on the ground, 8 on the plate) give the orientation outcomes of four times as many sweeps: the same
+    goal-known files reach the window, entering within one row of each other.  (The row on which `test` falls is not on a plateau: 22 for
+    28 ... 40 sweeps, one row later for 64 and 128; DESIGN.md 2.1 prints the table.)"""
+    a = run_all(robot_model, recordings, files=R.GOAL_KNOWN)
+    b = run_all(robot_model, recordings, files=R.GOAL_KNOWN, pgs_iters=128)
+    for name in a:
+        assert (a[name]["first_succ"] is None) == (b[name]["first_succ"] is None), name
+        if a[name]["first_succ"] is not None:
+            assert abs(a[name]["first_succ"] - b[name]["first_succ"]) <= 1, name
 
 
 # ---------------------------------------------------------------------------------------------------------------- HIP engine
@@ -104,22 +205,26 @@ def test_reference_npy_replay_hip(robot_model, recordings, oracle_runs):
         kind = R.kind_of(name)
         eng = Engine(robot_model, [R.cotrain_params("loco"), R.cotrain_params("mani")], 32, split_env=16, seed=0)
         e0 = 0 if kind == "loco" else 16
-        out_obs = torch.empty(32, 64, device="cuda")
+        out_obs = torch.empty(32, 64, device="cuda"); out_rew = torch.empty(32, device="cuda")
 
-        def step(a, eng=eng, e0=e0, kind=kind, out_obs=out_obs):
+        def step(a, eng=eng, e0=e0, kind=kind, out_obs=out_obs, out_rew=out_rew):
             act = torch.zeros(32, 12, device="cuda")
             act[(slice(0, 16) if kind == "loco" else slice(16, 32))] = torch.as_tensor(np.asarray(a, dtype=np.float32), device="cuda")
-            eng.step(act, out_obs=out_obs)
+            eng.step(act, out_obs=out_obs, out_rew=out_rew)
             torch.cuda.synchronize()
-            return (eng.state[13:25, e0].double().cpu().numpy(), eng.obs_buf[e0].double().cpu().numpy(), int(eng.cnt[3, e0]), int(eng.cnt[2, e0]))
-        runs[name] = R.replay(recordings[name], step)
+            return (eng.state[13:25, e0].double().cpu().numpy(), eng.obs_buf[e0].double().cpu().numpy(), int(eng.cnt[3, e0]), int(eng.cnt[2, e0]),
+                    float(out_rew[e0]))
+        runs[name] = R.replay(recordings[name], step, until_done=name in R.GOAL_KNOWN)
         print(R.summary_line(name, runs[name]))
         # all 16 envs of the half got the same actions from the same reset: they must agree bit for bit
         half = eng.state[13:25, (slice(0, 16) if kind == "loco" else slice(16, 32))]
         if runs[name]["done_at"] is None:
             assert (half == half[:, :1]).all()
         eng.close()
-    check_runs(runs)
+    check_drive_limit(runs)
+    check_orientation(runs)
+    check_row0(runs, recordings)
+    check_episode_reward(runs)
     # fp32 kernel vs fp64 oracle on the same open-loop actions: the first 8 steps (before chaos separates them) agree to 2e-3 rad
     for name in R.FILES:
         n = min(9, len(runs[name]["rows"]), len(oracle_runs[name]["rows"]))
