@@ -314,7 +314,7 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // their mutual coupling enters at the contact's next turn), then its three impulse increments are quad-broadcast and every
 // lane updates c.  Identical arithmetic (up to rounding) to the oracle's sweep over the dense 12x12 system.
 // Row layout: row 0 (normal) in plain registers, rows 1 | 2 (friction) as one packed pair.
-struct PgsData { float W00, rW0; f2 W0t, nrWt; float X0[4][3]; f2 X12[4][3]; };   // own block: W00, (W01 | W02), minus reciprocal diagonal (-1/W11 | -1/W22);
+struct PgsData { float nrW0; f2 W0t, nrWt; float X0[4][3]; f2 X12[4][3]; };   // own block: -1/W00, (W01 | W02), (-1/(mu W11) | -1/(mu W22)); columns 1, 2 of the X blocks carry mu;
                                                                                    // block towards contact K (K == own limb: the own block) by columns s: X0[K][s] = X[0][s], X12[K][s] = (X[1][s] | X[2][s])
 
 // ---- "four 6-vectors at once" layout of the pass linear algebra.  Component i of the vectors (v0, v1, v2, v3) is an R4: p = (v0[i] | v1[i]),
@@ -385,18 +385,20 @@ LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float
 }
 
 // One Gauss-Seidel turn: contact K relaxes its normal row, then its two friction rows as a pair (both from the state the normal row
-// left), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies c += X[K] * d.  Lanes whose
-// turn it is not run the same instructions on their own (discarded) candidates; only `lam` is guarded.
+// left), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies c += X[K] * d.  The relaxation
+// runs under the owner lanes' execution mask (a real branch, not selects: the three other lanes of the quad have nothing to compute and the
+// impulses are updated in place); the friction impulses are carried divided by mu, so that their bound is the normal impulse itself and mu
+// sits in the constants (nrWt, columns 1 and 2 of the X blocks).
 template <int K>
-LM_DEV void pgs_turn(int limb, float mu, const PgsData& G, float& lam0, f2& lam12, float& c0, f2& c12) {
-  const bool mine = (limb == K);
-  const float ln = fmaxf(0.0f, fmaf(-c0, G.rW0, lam0));
-  const float d0 = ln - lam0;
-  const float lim = mu * ln;
-  const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
-  const f2 l12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lim, lim), __builtin_amdgcn_fmed3f(u12.y, -lim, lim));
-  const f2 d12 = l12 - lam12;
-  lam0 = mine ? ln : lam0; lam12 = mk2(mine ? l12.x : lam12.x, mine ? l12.y : lam12.y);
+LM_DEV void pgs_turn(int limb, const PgsData& G, float& lam0, f2& lam12, float& c0, f2& c12, float& d0, f2& d12) {
+  if (limb == K) {
+    d0 = __builtin_amdgcn_fmed3f(c0 * G.nrW0, -lam0, __builtin_inff());      // max(-lam0, -c0 / W00) as one v_med3 (no canonicalising copy of -lam0)
+    lam0 += d0;
+    const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
+    const f2 l12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lam0, lam0), __builtin_amdgcn_fmed3f(u12.y, -lam0, lam0));
+    d12 = l12 - lam12;
+    lam12 = l12;
+  }
   const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d12.x), b2 = quad_bcast<K>(d12.y);
   c0 = fmaf(G.X0[K][0], b0, fmaf(G.X0[K][1], b1, fmaf(G.X0[K][2], b2, c0)));
   c12 = fma_(G.X12[K][0], sp2(b0), fma_(G.X12[K][1], sp2(b1), fma_(G.X12[K][2], sp2(b2), c12)));
@@ -417,25 +419,31 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
     Wf[0] = Wl[0] + b0; Wf[1] = Wl[1] + a0.x; Wf[2] = Wl[2] + a0.y;
     Wf[3] = Wl[3] + a1.x; Wf[4] = Wl[4] + a1.y; Wf[5] = Wl[5] + a2.y;
   }
-  G.W00 = Wf[0]; G.rW0 = 1.0f / Wf[0]; G.W0t = mk2(Wf[1], Wf[2]); G.nrWt = mk2(-1.0f / Wf[3], -1.0f / Wf[5]);
+  // friction impulses are carried as lam_t / mu (bound = the normal impulse); mu = 0 pins them at zero
+  const float imu = mu > 0.f ? 1.0f / mu : 0.f;
+  G.nrW0 = -1.0f / Wf[0]; G.W0t = mk2(Wf[1], Wf[2]); G.nrWt = mk2(-imu / Wf[3], -imu / Wf[5]);
   pgs_cross_blocks<0>(limb, T, X, Wf, G.X0[0], G.X12[0]); pgs_cross_blocks<1>(limb, T, X, Wf, G.X0[1], G.X12[1]);
   pgs_cross_blocks<2>(limb, T, X, Wf, G.X0[2], G.X12[2]); pgs_cross_blocks<3>(limb, T, X, Wf, G.X0[3], G.X12[3]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { G.X0[k][1] *= mu; G.X0[k][2] *= mu; G.X12[k][1] = sp2(mu) * G.X12[k][1]; G.X12[k][2] = sp2(mu) * G.X12[k][2]; }
   float lam0 = 0.f; f2 lam12 = sp2(0.f);
   float c0 = vf[0] + bn; f2 c12 = mk2(vf[1], vf[2]);
+  float d0 = 0.f; f2 d12 = sp2(0.f);
   // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
   // ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
   for (int it = 0; it < iters; it += 2) {
-    pgs_turn<0>(limb, mu, G, lam0, lam12, c0, c12);
-    pgs_turn<1>(limb, mu, G, lam0, lam12, c0, c12);
-    pgs_turn<2>(limb, mu, G, lam0, lam12, c0, c12);
-    pgs_turn<3>(limb, mu, G, lam0, lam12, c0, c12);
+    pgs_turn<0>(limb, G, lam0, lam12, c0, c12, d0, d12);
+    pgs_turn<1>(limb, G, lam0, lam12, c0, c12, d0, d12);
+    pgs_turn<2>(limb, G, lam0, lam12, c0, c12, d0, d12);
+    pgs_turn<3>(limb, G, lam0, lam12, c0, c12, d0, d12);
     if (it + 1 < iters) {
-      pgs_turn<3>(limb, mu, G, lam0, lam12, c0, c12);
-      pgs_turn<2>(limb, mu, G, lam0, lam12, c0, c12);
-      pgs_turn<1>(limb, mu, G, lam0, lam12, c0, c12);
-      pgs_turn<0>(limb, mu, G, lam0, lam12, c0, c12);
+      pgs_turn<3>(limb, G, lam0, lam12, c0, c12, d0, d12);
+      pgs_turn<2>(limb, G, lam0, lam12, c0, c12, d0, d12);
+      pgs_turn<1>(limb, G, lam0, lam12, c0, c12, d0, d12);
+      pgs_turn<0>(limb, G, lam0, lam12, c0, c12, d0, d12);
     }
   }
+  lam12 = sp2(mu) * lam12;
   lam[0] = lam0; lam[1] = lam12.x; lam[2] = lam12.y;
   // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
 #pragma unroll

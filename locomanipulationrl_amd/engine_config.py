@@ -23,8 +23,10 @@ trajectories (tests/golden/npy_traj.npz; tests/npy_replay
       and row 0 of the same recordings (the joints give way by 3e-3 ... 1.25e-2 rad while the scene settles) is reproduced only by a
       drive that yields at about 1.5 N m - no single reading fits both, see DESIGN.md 2.2.  `drive_limits_are_impulses=False` selects
       the torque reading; bench.py reports the headline under both.
-  pgs_iters 32 on the ground, 8 on the plate (round 3): the replay's orientation outcomes are those of the converged contact solve
-      from 28 Gauss-Seidel sweeps on (identical for 28 ... 128) on the ground; on the plate they are identical from 8 to 256 sweeps.
+  pgs_iters 16 on the ground, 8 on the plate (round 3): from 12 Gauss-Seidel sweeps on (12 ... 128 tabulated) the ground replays give
+      the same orientation outcomes - the same three of four locomotion files enter PhysX's success window, within one row of each other;
+      with 8 sweeps (round 2) one of four did.  16 is also the reference's own solver_position_iteration_count
+      (cfg/task/QuadrupedPoseControl.yaml:41).  On the plate the outcomes are identical from 8 to 256 sweeps.
 """
 from __future__ import annotations
 
@@ -32,7 +34,7 @@ from dataclasses import dataclass, field, replace
 from typing import List
 
 
-PGS_ITERS_GROUND, PGS_ITERS_PLATE = 32, 8
+PGS_ITERS_GROUND, PGS_ITERS_PLATE = 16, 8
 MODE_LOCO = 0    # free base on a ground plane
 MODE_MANI = 1    # fixed (inverted) base + free plate
 DRIVE_VELOCITY, DRIVE_POSITION, DRIVE_EFFORT = 0, 1, 2
@@ -70,7 +72,7 @@ class EngineParams:
     # ---- physics
     dt: float = 0.0083
     substeps: int = 4
-    pgs_iters: int = -1                 # contact sweeps per solve; -1 = by contact surface: 32 on the ground, 8 on the plate (see above)
+    pgs_iters: int = -1                 # contact sweeps per solve; -1 = by contact surface: 16 on the ground, 8 on the plate (see above)
     gravity: float = 9.81
     kd: float = 100.0
     max_effort: float = 1.5             # ArticulationView.set_max_efforts (robot.py:347-355); host-side only, tau_max is what the engine reads
