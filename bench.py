@@ -13,8 +13,11 @@ the size of the rollout's returns + advantages -- over RCCL, inside the timed re
 
 Rank 0 also reports, outside the timed region: the same workload through the drop-in boundary itself (`VecEnvRLGames.step`,
 `config.vec_env_step_env_steps_per_s`: fresh output tensors and the extras dict per call, as the reference's wrapper hands them out),
-the zero-action protocol of SURVEY 8(d) and the same envs with the reference's MLP policy in the loop (BASELINE config 2 names one):
-48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`).
+the zero-action protocol of SURVEY 8(d), the same envs with the reference's MLP policy in the loop (BASELINE config 2 names one):
+48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`), the headline workload under the OTHER reading of the drive
+limit (`config.torque_clamp_reading_env_steps_per_s`: max effort 1.5 as a 1.5 N m torque clamp; the default reads it as PhysX's per-step
+impulse limit - parity unpinned), BASELINE config 3 and config 4's per-GPU block (`config.manipulation_...`,
+`config.cotrain_block_...`) and one PD-actuator task family (`config.pd_family_...`).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts `torch.distributed.run` with N ranks as a child BEFORE
 touching the GPU and exits with its code.
@@ -36,7 +39,7 @@ BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (SURVEY 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE / flop counters, tools/profile_round.sh): counters cannot be
 # collected from inside the run, so `roofline.traffic` and `valu.flop_per_env_step` are READ FROM the newest of these files and labelled so
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json",)]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json")]
 
 
 def _omp_threads(n):
@@ -163,12 +166,18 @@ def main():
     payload = torch.zeros(2, ROLLOUT, N, device=dev)
     gathered = torch.empty(2 * world, ROLLOUT, N, device=dev) if world > 1 else None
 
-    def one_step(t):
+    ag_events = []                                           # HIP events around each all-gather block of the timed region (world > 1)
+
+    def one_step(t, timed=False):
         k = t % ROLLOUT
         eng.step(pool[t % 64], None, out_obs[t & 1], out_states[t & 1], roll_rew[k], roll_done[k], out_extras)
         if world > 1 and k == ROLLOUT - 1:
+            if timed:
+                ag_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))); ag_events[-1][0].record()
             payload[0].copy_(roll_rew); payload[1].copy_(roll_done)
             dist.all_gather_into_tensor(gathered, payload)
+            if timed:
+                ag_events[-1][1].record()
 
     def barrier():
         if world > 1:
@@ -183,7 +192,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for t in range(args.steps):
-        one_step(args.warmup + t)
+        one_step(args.warmup + t, timed=True)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -206,7 +215,8 @@ def main():
             a.record(); eng.step(pool[i % 64], None, out_obs[0], out_states[0], roll_rew[0], roll_done[0], out_extras); b.record()
         torch.cuda.synchronize(dev)
         k_ms = sorted(a.elapsed_time(b) for a, b in evs) or [region_ms / args.steps]
-        k_avg_ms = region_ms / args.steps
+        step_period_ms = region_ms / args.steps                                            # launch period of the timed region, collectives included
+        k_avg_ms = (region_ms - sum(a.elapsed_time(b) for a, b in ag_events)) / args.steps      # ... without the all-gather blocks: k_step's launch period
         achieved = BYTES_PER_ENV_STEP * N / (k_avg_ms * 1e-3) / 1e9
         pmc_file = next((f for f in PMC_FILES if os.path.exists(f)), None)
         pmc = json.load(open(pmc_file)) if pmc_file else None
@@ -252,18 +262,48 @@ def main():
             for _ in range(20): ro.run("auto"); ro.obs[0].copy_(ro.obs[ROLLOUT])
             torch.cuda.synchronize(dev); mlp_rate = N * ROLLOUT * 20 / (time.perf_counter() - tr)
             ro.close()
+        # other workloads of the path, same protocol (fresh U(-1,1) actions, 4096 envs), rank 0, untimed region: BASELINE config 3, config 4's
+        # per-GPU block, one PD-actuator family, and the headline under the torque-clamp reading of the drive limit
+        def rate_of(params, split=None, obs=64, steps=600):
+            e2 = Engine(load_model("quadruped_robot_v2"), params, N, seed=42, device=str(dev), **({} if split is None else dict(split_env=split)))
+            oo, ss = torch.empty(N, obs, device=dev), torch.empty(N, 93, device=dev)
+            for i in range(100): e2.step(pool[i % 64], None, oo, ss, roll_rew[0], roll_done[0], out_extras)
+            torch.cuda.synchronize(dev); t_ = time.perf_counter()
+            for i in range(steps): e2.step(pool[i % 64], None, oo, ss, roll_rew[0], roll_done[0], out_extras)
+            torch.cuda.synchronize(dev); r_ = N * steps / (time.perf_counter() - t_)
+            e2.close()
+            return r_
+        extra_rates = {}
+        if not args.timed_only:
+            from locomanipulationrl_amd.engine_config import loco_cc_params, mani_params
+            cq = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]
+            extra_rates = {
+                "torque_clamp_reading_env_steps_per_s": rate_of([loco_params(drive_limits_are_impulses=False)]),
+                "manipulation_env_steps_per_s": rate_of([mani_params()]),
+                "cotrain_block_env_steps_per_s": rate_of([loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]),
+                                                          mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], split=N // 2),
+                "pd_family_env_steps_per_s": rate_of([loco_cc_params()], obs=88),
+            }
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if backend == "nccl" else "synthetic (REHEARSAL over gloo, ranks share GPUs: not a measurement)",
             "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
-                                   "dt 0.0083 x 4 sub-steps, 8 PGS sweeps, obs 64 / states 93",
+                                   "dt 0.0083 x 4 sub-steps, 16 PGS sweeps, obs 64 / states 93",
                        "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
+                       # `value` divides by the wall clock around the timed region INCLUDING its closing barrier + synchronize (at 20 steps that
+                       # tail is a fifth of the window); the same region by the HIP events on the launch stream, rank 0:
+                       "event_timed_env_steps_per_s_rank0": N * args.steps / (region_ms * 1e-3),
                        "vec_env_step_env_steps_per_s": vec_rate,
                        "zero_action_env_steps_per_s_rank0": zero_rate,
-                       "mlp_policy_in_loop_env_steps_per_s_rank0": mlp_rate, "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
+                       "mlp_policy_in_loop_env_steps_per_s_rank0": mlp_rate, **extra_rates,
+                       "drive_limit_reading": "max effort 1.5 read as PhysX's per-step impulse limit (never binds); parity unpinned, the torque-clamp reading is timed beside it",
+                       "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step", "kernel_ms": k_avg_ms, "kernel_ms_single_launch_events": k_ms[len(k_ms) // 2],
+                         "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step",
+                         "kernel_ms": k_avg_ms, "kernel_ms_definition": "HIP events around the timed region on the launch stream, minus the all-gather blocks, / steps = k_step's launch "
+                                                                        "period (its duration + ~3.5 us between dependent launches; rocprofv3's average duration is in profiles/)",
+                         "step_period_ms": step_period_ms, "kernel_ms_single_launch_events": k_ms[len(k_ms) // 2],
                          "note": "1488 algorithmic B/env-step x 4096 envs per launch; the path is fp32-VALU / latency bound, see 'valu'"},
             # one wavefront per SIMD at 4096 envs: the binding resource is the wavefront's own instruction stream (fp32 VALU issue slots +
             # exposed latency), reported from the PMC passes; `step_quad_cycles` = this run's kernel time in quad-cycles at 2.4 GHz

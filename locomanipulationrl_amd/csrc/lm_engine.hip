@@ -385,20 +385,19 @@ LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float
 }
 
 // One Gauss-Seidel turn: contact K relaxes its normal row, then its two friction rows as a pair (both from the state the normal row
-// left), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies c += X[K] * d.  The relaxation
-// runs under the owner lanes' execution mask (a real branch, not selects: the three other lanes of the quad have nothing to compute and the
-// impulses are updated in place); the friction impulses are carried divided by mu, so that their bound is the normal impulse itself and mu
-// sits in the constants (nrWt, columns 1 and 2 of the X blocks).
+// left), then its three impulse increments are quad-broadcast and EVERY lane, the owner included, applies c += X[K] * d.  Lanes whose
+// turn it is not run the same instructions on their own (discarded) candidates; the impulses move by  m * d  with m = 1 on the owner
+// lane and 0 elsewhere (one FMA instead of an add and a select).  The friction impulses are carried divided by mu, so that their bound
+// is the normal impulse itself and mu sits in the constants (nrWt, columns 1 and 2 of the X blocks).
+// Measured alternatives (tools/ab_build.py, profiles/r03_pgs_turn_ab.json): the relaxation as a real branch under the owner lanes'
+// execution mask (18 vector + 3 scalar instructions per turn) is 14 % SLOWER per sweep than selects (20 vector instructions).
 template <int K>
-LM_DEV void pgs_turn(int limb, const PgsData& G, float& lam0, f2& lam12, float& c0, f2& c12, float& d0, f2& d12) {
-  if (limb == K) {
-    d0 = __builtin_amdgcn_fmed3f(c0 * G.nrW0, -lam0, __builtin_inff());      // max(-lam0, -c0 / W00) as one v_med3 (no canonicalising copy of -lam0)
-    lam0 += d0;
-    const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
-    const f2 l12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lam0, lam0), __builtin_amdgcn_fmed3f(u12.y, -lam0, lam0));
-    d12 = l12 - lam12;
-    lam12 = l12;
-  }
+LM_DEV void pgs_turn(float m, const PgsData& G, float& lam0, f2& lam12, float& c0, f2& c12) {
+  const float d0 = __builtin_amdgcn_fmed3f(c0 * G.nrW0, -lam0, __builtin_inff());      // max(-lam0, -c0 / W00) as one v_med3 (no canonicalising copy of -lam0)
+  lam0 = fmaf(m, d0, lam0);                                                            // owner: the relaxed normal impulse, which bounds its friction rows
+  const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
+  const f2 d12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lam0, lam0), __builtin_amdgcn_fmed3f(u12.y, -lam0, lam0)) - lam12;
+  lam12 = fma_(sp2(m), d12, lam12);
   const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d12.x), b2 = quad_bcast<K>(d12.y);
   c0 = fmaf(G.X0[K][0], b0, fmaf(G.X0[K][1], b1, fmaf(G.X0[K][2], b2, c0)));
   c12 = fma_(G.X12[K][0], sp2(b0), fma_(G.X12[K][1], sp2(b1), fma_(G.X12[K][2], sp2(b2), c12)));
@@ -428,19 +427,19 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
   for (int k = 0; k < 4; k++) { G.X0[k][1] *= mu; G.X0[k][2] *= mu; G.X12[k][1] = sp2(mu) * G.X12[k][1]; G.X12[k][2] = sp2(mu) * G.X12[k][2]; }
   float lam0 = 0.f; f2 lam12 = sp2(0.f);
   float c0 = vf[0] + bn; f2 c12 = mk2(vf[1], vf[2]);
-  float d0 = 0.f; f2 d12 = sp2(0.f);
+  const float m0 = limb == 0 ? 1.f : 0.f, m1 = limb == 1 ? 1.f : 0.f, m2 = limb == 2 ? 1.f : 0.f, m3 = limb == 3 ? 1.f : 0.f;
   // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
   // ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
   for (int it = 0; it < iters; it += 2) {
-    pgs_turn<0>(limb, G, lam0, lam12, c0, c12, d0, d12);
-    pgs_turn<1>(limb, G, lam0, lam12, c0, c12, d0, d12);
-    pgs_turn<2>(limb, G, lam0, lam12, c0, c12, d0, d12);
-    pgs_turn<3>(limb, G, lam0, lam12, c0, c12, d0, d12);
+    pgs_turn<0>(m0, G, lam0, lam12, c0, c12);
+    pgs_turn<1>(m1, G, lam0, lam12, c0, c12);
+    pgs_turn<2>(m2, G, lam0, lam12, c0, c12);
+    pgs_turn<3>(m3, G, lam0, lam12, c0, c12);
     if (it + 1 < iters) {
-      pgs_turn<3>(limb, G, lam0, lam12, c0, c12, d0, d12);
-      pgs_turn<2>(limb, G, lam0, lam12, c0, c12, d0, d12);
-      pgs_turn<1>(limb, G, lam0, lam12, c0, c12, d0, d12);
-      pgs_turn<0>(limb, G, lam0, lam12, c0, c12, d0, d12);
+      pgs_turn<3>(m3, G, lam0, lam12, c0, c12);
+      pgs_turn<2>(m2, G, lam0, lam12, c0, c12);
+      pgs_turn<1>(m1, G, lam0, lam12, c0, c12);
+      pgs_turn<0>(m0, G, lam0, lam12, c0, c12);
     }
   }
   lam12 = sp2(mu) * lam12;

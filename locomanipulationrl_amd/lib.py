@@ -100,6 +100,19 @@ def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParam
     return p
 
 
+def hipcc_command(extra, out):
+    """The ONE hipcc command line of the engine: the product build and every diagnostic build (tools/stamp_profile*.py, tools/ab_build.py: `extra` =
+    their -D switches) compile with the same flags, so that a diagnostic library measures the product's code."""
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    # -fno-slp-vectorize: the SLP vectoriser's own packed-fp32 pairs cost more v_mov / AGPR shuffles than they save (round 1: 56.0 -> 58.2 M
+    #   env-steps/s without it); the packed fp32 the kernel relies on is written by hand on the f2 type (lm_math.h) and is not affected
+    # -fno-hip-fp32-correctly-rounded-divide-sqrt: 1/x and sqrt as v_rcp / v_sqrt (1 ulp) instead of the ~10-instruction IEEE sequences
+    # -amdgpu-mfma-vgpr-form: the MFMA accumulators of the policy tiles live in ordinary VGPRs, so the VALU work on them (ELU, max aggregation,
+    # LDS stores) needs no v_accvgpr_read per element (504 of them in k_gnn_forward)
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+            "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", *extra, os.path.join(_CSRC, "lm_engine.hip"), os.path.join(_CSRC, "lm_policy.hip"), "-o", out]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/lm_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_CSRC, "lm_engine.hip")
@@ -109,13 +122,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     deps = sorted(glob.glob(os.path.join(_CSRC, "*.hip")) + glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(inc, "*.h")))      # every source the .so is built from
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
-    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-    # -fno-slp-vectorize: packed fp32 pairs cost more v_mov / AGPR shuffles than they save here (measured: 56.0 -> 58.2 M env-steps/s)
-    # -fno-hip-fp32-correctly-rounded-divide-sqrt: 1/x and sqrt as v_rcp / v_sqrt (1 ulp) instead of the ~10-instruction IEEE sequences
-    # -amdgpu-mfma-vgpr-form: the MFMA accumulators of the policy tiles live in ordinary VGPRs, so the VALU work on them (ELU, max aggregation,
-    # LDS stores) needs no v_accvgpr_read per element (504 of them in k_gnn_forward)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", src, src2, "-o", _SO]
+    cmd = hipcc_command(extra=[], out=_SO)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,6 +1,6 @@
 """Where k_step's time goes (4096 envs, loco): the runtime parameters switch phases off, so the differences are phase costs.
     substeps 4 -> 1 : per-sub-step cost and the fixed part (load, reset, task layer, outputs)
-    pgs_iters 8 -> 0 : the contact solver sweeps;  tau_max 180.7 -> 1.5 : round 1's torque clamp, under which most sub-steps run the second active-set pass"""
+    pgs_iters 0 / 8 / 16 / 32 : the contact solver sweeps (16 is the default on the ground);  tau_max 180.7 -> 1.5 : round 1's torque clamp, under which most sub-steps run the second active-set pass"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,10 @@ def run(N, steps=400, warmup=50, **kw):
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    cases = {"default": {}, "pgs0": dict(pgs_iters=0), "torque_clamp_1.5": dict(tau_max=1.5), "torque_clamp_1.5_pgs0": dict(tau_max=1.5, pgs_iters=0),
+    cases = {"default": {}, "pgs0": dict(pgs_iters=0), "pgs8": dict(pgs_iters=8), "pgs16": dict(pgs_iters=16), "pgs32": dict(pgs_iters=32),
+             "torque_clamp_1.5": dict(tau_max=1.5), "torque_clamp_1.5_pgs0": dict(tau_max=1.5, pgs_iters=0),
              "sub1": dict(substeps=1), "sub1_pgs0": dict(substeps=1, pgs_iters=0), "sub8": dict(substeps=8)}
+    if len(sys.argv) > 2:
+        cases = {k: cases[k] for k in sys.argv[2].split(",")}
     res = {k: run(N, **v) for k, v in cases.items()}
-    print(json.dumps({"envs": N, "us_per_step": res}))
+    print(json.dumps({"envs": N, "library": os.environ.get("LM_ENGINE_SO", "product"), "us_per_step": res}))

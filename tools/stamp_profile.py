@@ -11,11 +11,10 @@ NAMES = {0: "entry: physical-state loads, table to LDS", 1: "sub-steps: limb kin
          8: "state stores", 9: "partial sums, atomics + output stores issued", 10: "reduction round trips (this wavefront's)", 12: "(cost of one stamp)"}
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    csrc = os.path.join(ROOT, "locomanipulationrl_amd", "csrc")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-                           "-fPIC", "-shared", "-DLM_STAMPS", os.path.join(csrc, "lm_engine.hip"), os.path.join(csrc, "lm_policy.hip"), "-o", SO])
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-                           "-fPIC", "-shared", "-DLM_STAMPS=2", os.path.join(csrc, "lm_engine.hip"), os.path.join(csrc, "lm_policy.hip"), "-o", SO.replace("stamps.so", "lifetime.so")])
+    sys.path.insert(0, ROOT)
+    from locomanipulationrl_amd.lib import hipcc_command      # the product's own flags + the stamp switch
+    subprocess.check_call(hipcc_command(extra=["-DLM_STAMPS"], out=SO))
+    subprocess.check_call(hipcc_command(extra=["-DLM_STAMPS=2"], out=SO.replace("stamps.so", "lifetime.so")))
     print("built", SO); sys.exit(0)
 if "--lifetime" in sys.argv: SO = SO.replace("stamps.so", "lifetime.so")
 os.environ["LM_ENGINE_SO"] = SO

@@ -4,9 +4,9 @@ import ctypes as C, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tools", "diag", "liblm_engine_gnnstamps.so")
 if "--build" in sys.argv:
-    csrc = os.path.join(ROOT, "locomanipulationrl_amd", "csrc")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-                           "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", "-DLM_GNN_STAMPS", os.path.join(csrc, "lm_engine.hip"), os.path.join(csrc, "lm_policy.hip"), "-o", SO])
+    sys.path.insert(0, ROOT)
+    from locomanipulationrl_amd.lib import hipcc_command      # the product's own flags + the stamp switch
+    subprocess.check_call(hipcc_command(extra=["-DLM_GNN_STAMPS"], out=SO))
     print("built", SO); sys.exit(0)
 os.environ["LM_ENGINE_SO"] = SO
 sys.path.insert(0, ROOT)
