@@ -41,6 +41,11 @@ extern "C" {
 #define LM_NUM_EXTRAS 13  /* 7 reward-term means, success_rate, success_rate of task 0 / task 1 (co-train),
                              custom-controller means: mechanical_power, position_target_error, rot_dist_decreasing */
 #define LM_TABLE_FLOATS 502  /* 10 hub + 4 x 123 limb (RobotModel.packed_table) */
+/* Bumped whenever lm_params, the table layout or the meaning of an entry point changes.  Every lm_params block carries it together with the
+ * caller's sizeof(lm_params) and LM_TABLE_FLOATS (first three fields); lm_create returns LM_EINVAL when any of them differs from what the
+ * library was built with, instead of reading a shifted struct or past the end of a shorter table.
+ *   1  round 1     2  round 2 (drive_mode, 502-float table; not stamped)     3  round 3 (the stamp itself; pgs_iters per contact surface) */
+#define LM_ABI_VERSION 3
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
  * sources in the reference are cited there. */
@@ -66,6 +71,10 @@ typedef struct lm_dr_channel {
 #define LM_DR_CNT_ROWS 5   /* int64 [row][N]: observation noise counter, action noise counter, dr_step, randomization_buf, dr_reset_key */
 
 typedef struct lm_params {
+  int32_t abi_version;     /* LM_ABI_VERSION of the header the caller was compiled against */
+  int32_t params_size;     /* the caller's sizeof(lm_params) */
+  int32_t table_floats;    /* the caller's LM_TABLE_FLOATS = the length of the table it passes to lm_create */
+  int32_t reserved0;       /* 0 */
   float dt, kd, tau_max, act_scale, mu, tip_radius, baumgarte, max_depen_vel, max_joint_vel, gravity;
   int32_t substeps, pgs_iters, mode;
   float fixed_base_pos[3], fixed_base_quat[4];
@@ -182,6 +191,7 @@ int lm_num_obs(const lm_engine* h);      /* observation width of this engine (64
 int lm_set_seed(lm_engine* h, uint32_t seed);
 const char* lm_last_error(void);
 const char* lm_version(void);
+int lm_abi_version(void);                /* LM_ABI_VERSION the library was built with */
 
 #ifdef __cplusplus
 }

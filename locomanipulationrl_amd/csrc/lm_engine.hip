@@ -1748,13 +1748,19 @@ static void derive_params(lm_params* p) {
 extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
-const char* lm_version(void) { return "lm_engine 0.1 (gfx950)"; }
+const char* lm_version(void) { return "lm_engine 0.3 (gfx950, abi 3)"; }
+int lm_abi_version(void) { return LM_ABI_VERSION; }
 
 int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks, int split_env, uint32_t seed) {
   if (!out || !table || !params) return fail(LM_EINVAL, "lm_create: null argument");
   if (n_envs <= 0) return fail(LM_EINVAL, "lm_create: n_envs must be positive");
   if (n_envs >= (1 << (ACC_WIN_BITS - 1))) return fail(LM_EINVAL, "lm_create: n_envs must be below 2^25 per engine (width of the reset counts in the extras reduction)");
   if (n_tasks != 1 && n_tasks != 2) return fail(LM_EINVAL, "lm_create: n_tasks must be 1 or 2");
+  // the stamp of the FIRST block is read before anything else of the struct: a caller built against another header passes a shifted layout
+  if (params[0].abi_version != LM_ABI_VERSION || params[0].params_size != (int32_t)sizeof(lm_params) || params[0].table_floats != LM_TABLE_FLOATS)
+    return fail(LM_EINVAL, "lm_create: ABI mismatch (lm_params.abi_version / params_size / table_floats differ from the library's LM_ABI_VERSION, sizeof(lm_params), LM_TABLE_FLOATS)");
+  if (n_tasks == 2 && (params[1].abi_version != LM_ABI_VERSION || params[1].params_size != (int32_t)sizeof(lm_params) || params[1].table_floats != LM_TABLE_FLOATS))
+    return fail(LM_EINVAL, "lm_create: ABI mismatch in the second parameter block");
   if (n_tasks == 2 && (split_env <= 0 || split_env >= n_envs || (split_env % ENVS_PER_WAVE) != 0))
     return fail(LM_EINVAL, "lm_create: split_env must be a multiple of 16 inside (0, n_envs)");
   for (int t = 0; t < n_tasks; t++) {

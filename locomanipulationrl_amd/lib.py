@@ -21,7 +21,7 @@ PTR_STATE, PTR_CNT, PTR_OBS_BUF, PTR_STATES_BUF, PTR_REW_BUF, PTR_EXTRAS, PTR_ST
 
 # names of the exported C symbols (checked by tests/test_abi.py against include/lm_engine.h)
 EXPORTS = ["lm_create", "lm_destroy", "lm_step", "lm_post_physics", "lm_reset_all", "lm_task_eval", "lm_apply_resets", "lm_substeps",
-           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_num_obs", "lm_set_seed", "lm_last_error", "lm_version",
+           "lm_forward_kinematics", "lm_debug_dynamics", "lm_ptr", "lm_num_envs", "lm_num_obs", "lm_set_seed", "lm_last_error", "lm_version", "lm_abi_version",
            "lm_gnn_param_count", "lm_gnn_forward", "lm_mlp_param_count", "lm_mlp_forward", "lm_mlp_param_count_obs", "lm_mlp_forward_obs",
            "lm_sample_actions", "lm_rollout_create", "lm_rollout_run", "lm_rollout_destroy"]
 
@@ -36,8 +36,12 @@ class LmDrChannel(C.Structure):
                 ("p0", C.c_float * 3), ("p1", C.c_float * 3)]
 
 
+ABI_VERSION = 3          # LM_ABI_VERSION of include/lm_engine.h this mirror was written against
+
+
 class LmParams(C.Structure):
     _fields_ = [
+        ("abi_version", C.c_int32), ("params_size", C.c_int32), ("table_floats", C.c_int32), ("reserved0", C.c_int32),
         ("dt", C.c_float), ("kd", C.c_float), ("tau_max", C.c_float), ("act_scale", C.c_float), ("mu", C.c_float),
         ("tip_radius", C.c_float), ("baumgarte", C.c_float), ("max_depen_vel", C.c_float), ("max_joint_vel", C.c_float), ("gravity", C.c_float),
         ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("mode", C.c_int32),
@@ -65,12 +69,13 @@ class LmParams(C.Structure):
     ]
 
 
-_DERIVED = {"plate_si", "plate_phi", "ctrl_dt_inv", "acc_dt_inv"}
+_DERIVED = {"plate_si", "plate_phi", "ctrl_dt_inv", "acc_dt_inv", "abi_version", "params_size", "table_floats", "reserved0"}
 
 
 def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParams:
     """EngineParams -> C struct (clipObservations / clipActions: QuadrupedPoseControl.yaml:11-12)."""
     p = LmParams()
+    p.abi_version, p.params_size, p.table_floats = ABI_VERSION, C.sizeof(LmParams), TABLE_FLOATS      # the stamp lm_create checks
     for name, _ in LmParams._fields_:
         if name in _DERIVED:
             continue

@@ -86,7 +86,13 @@ class Randomizer:
         simulates are unchanged.  Here the entry is therefore ACCEPTED: the per-env factors are drawn as the reference draws them (one
         synchronised factor per env, torch generator seeded with the config seed, randomize.py:60,308-350) and kept in `startup_scales`
         for inspection, a warning says that they do not enter the dynamics, and the compiled model table stays shared by all envs.
-        mass / density on_startup entries would change that table per env and are refused."""
+        mass / density on_startup entries would change that table per env and are refused.
+        PARITY UNPINNED: whether PhysX rescales anything on `set_local_scales` rests on that question-marked author comment (the same line
+        sits in every task YAML of the reference, e.g. JointLocomanipulation.yaml:166), and the factors come from a private torch.Generator
+        seeded with the config seed, not from the global stream the reference seeds with `torch.manual_seed` before
+        `randomize_scale_on_startup` - `startup_scales` records this repo's draws, not the reference's.  The entry is accepted (with the
+        warning) rather than refused because the reference's own YAML block has to load entry for entry (`test_reference_dr_block_loads_verbatim`);
+        `sim.engine.refuse_startup_scale: true` turns the warning into a NotImplementedError for users who prefer the loud failure."""
         if not self.randomize:
             return
         import warnings
@@ -101,6 +107,8 @@ class Randomizer:
                     if not set(_ON_RESET_KEYS).issubset(st.keys()):          # randomize.py:75-77,104-106
                         raise ValueError(f"Please ensure the following randomization parameters for {view} {attribute} on_startup are provided: "
                                          "operation, distribution, distribution_parameters.")
+                    if attribute == "scale" and bool((self._cfg.get("sim", {}).get("engine", {}) or {}).get("refuse_startup_scale", False)):
+                        raise NotImplementedError(f"{group}.{view}.scale on_startup does not enter this engine's dynamics (sim.engine.refuse_startup_scale is set)")
                     if attribute != "scale":
                         raise NotImplementedError(f"domain randomisation of {group}.{view}.{attribute} on_startup is not implemented "
                                                   "(mass / density change the compiled model table per env)")

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
-"""Evidence table behind the two spec parameters round 2 moved: the open-loop replay of the reference's PhysX
-recordings (tests/npy_replay.py) under alternative readings of the drive limit, friction coefficients and foot geometries.
+"""Evidence tables behind the physics parameters chosen from the reference's PhysX recordings (DESIGN.md sections 2.1 and 2.2): the
+open-loop replay of tests/golden/npy_traj.npz (tests/npy_replay.py) under alternative sweep counts, friction coefficients, drive-limit
+readings, foot geometries and depenetration rules.
 
-    python tests/npy_replay_evidence.py [out.json]          (CPU, ~1 minute; test infrastructure: runs the oracle)
+    python tests/npy_replay_evidence.py [out.json]          (CPU, a few minutes; test infrastructure: runs the oracle)
 
-Columns: tracked = share of joint-steps whose displacement matches the recording to 1e-3 rad; early = mean |displacement error| over the
-first 4 steps (states still synchronised) in units of a full-scale step; qerr = worst joint position deviation over whole episodes [rad];
-servo_qerr = mean joint deviation when every step steers back onto the recording with actions inside +-1 (is the recorded motion feasible
-for the drive?); reached = goal-known files (7) that get inside the 0.15 rad success window, mean_min_rot_dist = their mean closest approach to the goal [rad]; test_row = row on which `test` terminates
-(PhysX: 22)."""
-import copy
+Tables
+  sweeps      per kind (locomotion 4 goal-known files / manipulation 3): files entering PhysX's 0.15 rad success window, their entry rows
+              against PhysX's, rows inside PhysX's window, the row on which `test` ends (PhysX 22) - for 8 ... 128 sweeps at mu 1.0 and 0.7
+  controls    the negative controls of tests/test_reference_npy_replay.py and the round-1 / round-2 specifications
+  drive       joint-level statistics (tracked = share of joint-steps whose displacement matches the recording to 1e-3 rad; early = mean
+              |displacement error| over the first 4 steps in units of a full-scale step; qerr = worst joint deviation) for readings of
+              `set_max_efforts(1.5)`: they test the drive limit and nothing else
+  row0        one control period after reset under zero action: max |q - recording| per kind for drive limit x depenetration rule; the
+              recorded deflection (4.2e-3 rad on the ground, 1.27e-2 rad under the plate) against this engine's
+  files       the per-file outcome of the shipped specification
+"""
 import json
 import os
 import sys
@@ -22,59 +28,84 @@ import npy_replay as R
 from locomanipulationrl_amd.model.robot_model import load_model
 
 
-def variant_model(rm, foot):
-    m = copy.deepcopy(rm)
-    if foot == "r1":          # round 1: a 2 mm sphere centred on the fingertip frame (on link3 for every module)
-        m.contact_body = m.tip_body.copy(); m.contact_off = m.tip_off.copy()
-    return m
+def run(rm, rec, files=None, until_done=False, **kw):
+    return {n: R.replay(rec[n], R.oracle_stepper(rm, R.cotrain_params(R.kind_of(n), **kw)), until_done=until_done) for n in (files or R.FILES)}
 
 
-def evaluate(rm, rec, foot="mesh", **kw):
-    m = variant_model(rm, foot)
-    if foot == "r1":
-        kw = dict(dict(tip_radius=0.002), **kw)
-    tr, early, qerr, sq, reached, test_row, early_term, minrd = [], [], [], [], 0, None, 0, []
-    for name in R.FILES:
-        ep = R.cotrain_params(R.kind_of(name), **kw)
-        r = R.replay(rec[name], R.oracle_stepper(m, ep))
-        s = R.replay(rec[name], R.oracle_stepper(m, ep), servo=True)
-        tr.append(r["tracked"]); early.append(r["early"]); qerr.append(r["qerr"])
-        sq.append(float(np.abs(s["rows"] - rec[name][:len(s["rows"])]).mean()))
-        if name in R.GOAL_KNOWN:
-            minrd.append(float(r["rd"].min()))
-            reached += r["first_succ"] is not None
-        if name == "test":
-            test_row = r["done_at"]
-        elif r["done_at"] is not None and r["done_at"] < r["T"] - 1 and name in R.GOAL_KNOWN:
-            early_term += 1
-    return dict(tracked=round(float(np.mean(tr)), 3), early=round(float(np.mean(early)), 4), qerr=round(float(np.max(qerr)), 3),
-                servo_qerr=round(float(np.mean(sq)), 4), reached=int(reached), mean_min_rot_dist=round(float(np.mean(minrd)), 3), early_terminations=early_term, test_row=test_row)
+def outcome(runs):
+    out = {}
+    for kind in ("loco", "mani"):
+        names = [n for n in R.GOAL_KNOWN if R.kind_of(n) == kind]
+        out[kind] = dict(reached=int(sum(runs[n]["first_succ"] is not None for n in names)), of=len(names),
+                         entry_rows=[runs[n]["first_succ"] for n in names], physx_rows=[runs[n]["succ_row"] for n in names],
+                         rows_in_physx_window=[runs[n]["in_window"] for n in names], closest=[round(float(runs[n]["rd_rec"].min()), 3) for n in names],
+                         early_end=[runs[n]["done_at"] if (runs[n]["done_at"] is not None and runs[n]["done_at"] < runs[n]["T"] - 1) else None for n in names])
+    out["test_ends_on"] = runs["test"]["done_at"] if "test" in runs else None
+    return out
+
+
+def joint_stats(runs):
+    return dict(tracked=round(float(np.mean([r["tracked"] for r in runs.values()])), 3), tracked_min=round(float(min(r["tracked"] for r in runs.values())), 3),
+                early=round(float(np.mean([r["early"] for r in runs.values()])), 4), qerr=round(float(max(r["qerr"] for r in runs.values())), 3))
+
+
+def fmt(o):
+    return " | ".join(f"{k} {o[k]['reached']}/{o[k]['of']} rows {o[k]['entry_rows']} (PhysX {o[k]['physx_rows']}) in-window {o[k]['rows_in_physx_window']}" for k in ("loco", "mani")) + f" | test ends on {o['test_ends_on']}"
 
 
 def main():
-    rm = load_model("quadruped_robot_v2"); rec = R.load()
-    dt = 0.0083
-    rows = [
-        ("round 1 spec: 1.5 N m torque clamp, mu 1.0, 2 mm tip sphere", dict(foot="r1", tau_max=1.5)),
-        ("1.5 N m clamp, mesh foot (5 mm hemisphere on the long link)", dict(tau_max=1.5)),
-        ("1.5 N m clamp, mesh foot, mu 0.5", dict(tau_max=1.5, mu=0.5)),
-        ("2.0 N m clamp (the USD's maxForce 2), mesh foot", dict(tau_max=2.0)),
-        ("3.0 N m clamp, mesh foot", dict(tau_max=3.0)),
-        ("6.0 N m clamp, mesh foot", dict(tau_max=6.0)),
-        ("impulse reading 1.5 / dt = 180.7 N m, 2 mm tip sphere", dict(foot="r1", tau_max=1.5 / dt)),
-        ("ROUND 2 SPEC: impulse reading, mesh foot, mu 1.0", dict(tau_max=1.5 / dt)),
-        ("impulse reading, mesh foot, mu 0.5", dict(tau_max=1.5 / dt, mu=0.5)),
-        ("impulse reading, mesh foot, mu 0.7", dict(tau_max=1.5 / dt, mu=0.7)),
-        ("impulse reading, mesh foot, mu 1.5", dict(tau_max=1.5 / dt, mu=1.5)),
-        ("impulse reading, mesh foot, mu 2.0", dict(tau_max=1.5 / dt, mu=2.0)),
-    ]
-    out = []
-    for label, kw in rows:
-        e = evaluate(rm, rec, **kw); e["variant"] = label; out.append(e)
-        print(f"{label:66s} tracked {e['tracked']:.3f}  early {e['early']:.4f}  qerr {e['qerr']:.3f}  servo {e['servo_qerr']:.4f}  "
-              f"reached {e['reached']}/7  min-rd {e['mean_min_rot_dist']:.3f}  early-term {e['early_terminations']}  test row {e['test_row']}", flush=True)
+    rm = load_model("quadruped_robot_v2"); rec = R.load(); dt = 0.0083
+    doc = {"source": "tests/npy_replay_evidence.py (CPU oracle fp64, open-loop replay of tests/golden/npy_traj.npz)"}
+    G = R.GOAL_KNOWN + ["test"]
+    print("== sweeps x friction (per kind)")
+    doc["sweeps"] = []
+    for mu in (1.0, 0.7):
+        for it in (8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 40, 64, 128):
+            o = outcome(run(rm, rec, G, pgs_iters=it, mu=mu)); o.update(pgs_iters=it, mu=mu); doc["sweeps"].append(o)
+            print(f"mu {mu} sweeps {it:3d}: {fmt(o)}", flush=True)
+    print("== negative controls and earlier specifications")
+    doc["controls"] = []
+    for label, kw in [("shipped specification", {}), ("gravity 0", dict(gravity=0.0)), ("friction 0", dict(mu=0.0)), ("one sweep", dict(pgs_iters=1)),
+                      ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5)), ("round 2: 8 sweeps on the ground", dict(pgs_iters=8))]:
+        runs = run(rm, rec, **kw); o = outcome(runs); o.update(variant=label, joints=joint_stats(runs)); doc["controls"].append(o)
+        print(f"{label:32s} {fmt(o)}  joints {o['joints']}", flush=True)
+    print("== readings of set_max_efforts(1.5): the joint-level statistics")
+    doc["drive"] = []
+    for label, kw in [("1.5 N m torque clamp", dict(tau_max=1.5)), ("2.0 N m (the USD's maxForce)", dict(tau_max=2.0)), ("3 N m", dict(tau_max=3.0)), ("6 N m", dict(tau_max=6.0)),
+                      ("impulse reading 1.5 / dt = 180.7 N m (shipped)", dict(tau_max=1.5 / dt)), ("impulse reading, gravity 0", dict(gravity=0.0)), ("impulse reading, friction 0", dict(mu=0.0)),
+                      ("soft drive kd 20", dict(kd=20.0)), ("soft drive kd 1.745 (= 100 pi / 180)", dict(kd=1.745))]:
+        j = joint_stats(run(rm, rec, **kw)); j["variant"] = label; doc["drive"].append(j)
+        print(f"{label:48s} {j}", flush=True)
+    print("== row 0: max |q - recording| [rad] (ground / plate); recorded deflection from the reset pose 4.2e-3 / 1.27e-2")
+    doc["row0"] = []
+    init = np.array(R.INIT_Q)
+    for label, kw in [("shipped: impulse reading, Baumgarte 0.2 capped at 1 m/s", {}),
+                      ("impulse reading, uncapped depenetration (Baumgarte 0.8, 100 m/s)", dict(baumgarte=0.8, max_depen_vel=100.0)),
+                      ("1.5 N m clamp, Baumgarte 0.2 capped", dict(tau_max=1.5)),
+                      ("1.5 N m clamp, Baumgarte 0.5 uncapped", dict(tau_max=1.5, baumgarte=0.5, max_depen_vel=100.0)),
+                      ("1.5 N m clamp, Baumgarte 0.8 uncapped", dict(tau_max=1.5, baumgarte=0.8, max_depen_vel=100.0)),
+                      ("1.5 N m clamp, Baumgarte 1.0 uncapped", dict(tau_max=1.5, baumgarte=1.0, max_depen_vel=100.0)),
+                      ("3 N m clamp, Baumgarte 1.0 uncapped", dict(tau_max=3.0, baumgarte=1.0, max_depen_vel=100.0)),
+                      ("0.75 N m clamp, Baumgarte 0.2 capped", dict(tau_max=0.75))]:
+        row = dict(variant=label)
+        for kind, name in (("ground", "mlp_joint_loco"), ("plate", "mlp_joint_mani")):
+            q = R.oracle_stepper(rm, R.cotrain_params(R.kind_of(name), **kw))(np.zeros(12))[0]
+            row[kind] = dict(err=round(float(np.abs(q - rec[name][0]).max()), 5), engine_deflection=[round(float(x), 5) for x in (q - init)],
+                             physx_deflection=[round(float(x), 5) for x in (rec[name][0] - init)])
+        doc["row0"].append(row)
+        print(f"{label:66s} ground {row['ground']['err']:.4f}  plate {row['plate']['err']:.4f}", flush=True)
+    print("== per file (shipped specification; replays held still for up to 17 rows after the recording to let a late streak complete)")
+    doc["files"] = []
+    runs = run(rm, rec, until_done=False); held = run(rm, rec, R.GOAL_KNOWN, until_done=True)
+    for name in R.FILES:
+        r = runs[name]; h = held.get(name)
+        row = dict(file=name, rows=r["T"], row0_err=round(r["row0_err"], 4), tracked=round(r["tracked"], 3), qerr=round(r["qerr"], 3), early=round(r["early"], 4),
+                   terminates=r["done_at"], enters_window=r["first_succ"], physx_enters=r["succ_row"] if name in R.GOAL_KNOWN else None,
+                   rows_in_physx_window=r["in_window"] if name in R.GOAL_KNOWN else None, closest=round(float(r["rd_rec"].min()), 3), last=round(float(r["rd_rec"][-1]), 3),
+                   success_row_when_held=(h["done_at"] if (h and h["goal"]) else None), return_when_held=(round(float(h["rew"].sum()), 1) if h else None))
+        doc["files"].append(row); print(row, flush=True)
     if len(sys.argv) > 1:
-        json.dump({"source": "tests/npy_replay_evidence.py (CPU oracle, open-loop + servo replay of tests/golden/npy_traj.npz)", "rows": out}, open(sys.argv[1], "w"), indent=1)
+        json.dump(doc, open(sys.argv[1], "w"), indent=1)
 
 
 if __name__ == "__main__":

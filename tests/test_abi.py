@@ -32,7 +32,9 @@ def test_exports_match_header(so):
     assert set(names) == set(lmlib.EXPORTS), (names, lmlib.EXPORTS)
     for n in names:
         assert hasattr(so, n), f"{n} declared in lm_engine.h but not exported"
-    assert b"gfx950" in so.lm_version()
+    assert b"gfx950" in so.lm_version() and so.lm_abi_version() == lmlib.ABI_VERSION
+    hdr = open(HEADERS[0]).read()
+    assert int(re.search(r"#define LM_ABI_VERSION (\d+)", hdr).group(1)) == lmlib.ABI_VERSION
 
 
 def test_params_struct_layout_matches_c():
@@ -63,6 +65,12 @@ def test_argument_validation_without_gpu(so):
     tab = np.zeros(lmlib.TABLE_FLOATS, np.float32)
     arr = (lmlib.LmParams * 2)(lmlib.make_params(loco_params()), lmlib.make_params(loco_params()))
     assert so.lm_create(C.byref(h), -5, tab.ctypes.data_as(C.c_void_p), arr, 1, 0, 0) == -1
+    # a caller built against another header: wrong version stamp, a shorter struct, a shorter table -> LM_EINVAL before anything else is read
+    for field, value in (("abi_version", lmlib.ABI_VERSION - 1), ("params_size", C.sizeof(lmlib.LmParams) - 4), ("table_floats", 486)):
+        stale = (lmlib.LmParams * 1)(lmlib.make_params(loco_params())); setattr(stale[0], field, value)
+        assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), stale, 1, 0, 0) == -1 and b"ABI mismatch" in so.lm_last_error(), field
+    stale = (lmlib.LmParams * 2)(lmlib.make_params(loco_params()), lmlib.make_params(loco_params())); stale[1].abi_version = 2
+    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), stale, 2, 32, 0) == -1 and b"second parameter block" in so.lm_last_error()
     assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), arr, 3, 0, 0) == -1
     assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), arr, 2, 24, 0) == -1     # split not a multiple of 16
     bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(dt=0.0)))

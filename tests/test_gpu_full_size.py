@@ -69,13 +69,21 @@ def test_config4_cotrain_block_2048_2048():
             generic_invariants(task, out)
             s = task.engine.state
             assert (s[3:7, :h].norm(dim=0) - 1).abs().max() < 1e-5 and (s[40:44, h:].norm(dim=0) - 1).abs().max() < 1e-5
-            # locomotion half: bases near their drop point; manipulation half: plates above the inverted robots fixed at z 0.5
+            # locomotion half: bases near their drop point; manipulation half: plates around the inverted robots fixed at z 0.5.
+            # Why the plate bound is 0.3 and not the robots' 0.5: a plate that random actions have thrown off the feet is reset by the task's
+            # own tests, all of which are written in the PLATE frame (quadruped_manipulate_plate.py:576-603: robot base / corners / knees
+            # against the plate's plane), not by its world height - a tilted plate sliding past the frame edge can be 5-20 cm below the base
+            # plane for the few steps until the corner or knee test fires (0.449 was seen in round 2).  0.3 = a plate's half-width below the base.
             assert float(s[2, :h].min()) > 0.0 and float(s[2, :h].max()) < 0.3 and float(s[39, h:].min()) > 0.3 and float(s[39, h:].max()) < 1.0
             ex = out[3]
             for k in ("env/success_rate", "env/success_rate_loco", "env/success_rate_mani"):
                 assert 0.0 <= float(ex[k]) <= 1.0
-            st = task.engine.stats_i64          # {successes, resets} x {all, first half, second half}: three windows, each emptied on its own
-            assert all(0 <= int(st[2 * k]) <= int(st[2 * k + 1]) <= 2048 + N for k in range(3))      # when it passes 2048 resets (joint_locomanipulation.py:795-830)
+            # {successes, resets} x {all, first half, second half}.  The three windows are NOT additive ("halves add up to the whole" was
+            # asserted in round 2's first draft and is wrong): the reference keeps three independent counters and empties each one on its own
+            # when IT passes max_reset_counts = 2048 (joint_locomanipulation.py:795-830: success_rate, success_rate_loco, success_rate_mani
+            # are reset in three separate `if` blocks), so after the first roll-over they cover different spans of steps.
+            st = task.engine.stats_i64
+            assert all(0 <= int(st[2 * k]) <= int(st[2 * k + 1]) <= 2048 + N for k in range(3))
     assert res_l > 0 and res_m > 0
     env.close()
 

@@ -126,7 +126,7 @@ def episode_reward(r):
     if bonus:
         window -= 600.0 if r["done_at"] == T - 1 else 0.0            # the bonus is part of that row's reward when it falls inside the window
     lo, hi = 17 * (2.0 - 0.5) + 600.0, 17 * 5.0 + 600.0
-    return dict(ret=window + bonus, lo=lo, hi=hi, ok=bool(lo <= window + bonus <= hi), bonus_row=r["done_at"] if bonus else None)
+    return dict(ret=window + bonus, lo=lo, hi=hi, ok=bool(0.99 * lo <= window + bonus <= 1.01 * hi), bonus_row=r["done_at"] if bonus else None)      # to 1 %
 
 
 def check_episode_reward(runs_until_done):
