@@ -105,6 +105,9 @@ typedef struct lm_params {
                                 LM_DRIVE_VELOCITY  target = a * act_scale [rad/s]           implicit damper kd (the mode every task of the path uses)
                                 LM_DRIVE_POSITION  target = a * act_scale [rad] (act_scale = pi); tau = pd_kp (q* - q) - kd qd, re-evaluated per sub-step
                                 LM_DRIVE_EFFORT    tau = a * act_scale [N m] (act_scale = torque limit), gains off */
+  int32_t sat_probe;         /* variants 1 / 2: contact sweeps of the first drive pass after which drive saturation is tested (even, 2 ... pgs_iters;
+                                pgs_iters = after the full solve, which is what variant 0 always does).  Envs without a saturated joint continue the same solve to pgs_iters; the others are re-solved with their
+                                saturated joints at the constant limit torque and the full count.  DESIGN.md 3.3 */
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */

@@ -404,9 +404,9 @@ LM_DEV void pgs_turn(float m, const PgsData& G, float& lam0, f2& lam12, float& c
 }
 
 // T[i].p.y, T[i].q = this lane's three contact rows (hub / plate wrench per unit impulse); X[i].p.y, X[i].q = B = Phi T
-LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3], const float Wl[6],
-                      const R4 T[6], const R4 X[6], float lam[3], float w[6]) {
-  PgsData G; float Wf[6];
+struct PgsState { PgsData G; float lam0; f2 lam12; float c0; f2 c12; float m0, m1, m2, m3; };
+LM_DEV void pgs_setup(PgsState& S, int limb, float mu, float bn, const float vf[3], const float Wl[6], const R4 T[6], const R4 X[6]) {
+  PgsData& G = S.G; float Wf[6];
   // full own block = limb-local part + hub/plate part T_r^T Phi T_s
   {
     f2 a0 = sp2(0.f), a1 = sp2(0.f), a2 = sp2(0.f); float b0 = 0.f;
@@ -425,28 +425,32 @@ LM_DEV void pgs_solve(int iters, int limb, float mu, float bn, const float vf[3]
   pgs_cross_blocks<2>(limb, T, X, Wf, G.X0[2], G.X12[2]); pgs_cross_blocks<3>(limb, T, X, Wf, G.X0[3], G.X12[3]);
 #pragma unroll
   for (int k = 0; k < 4; k++) { G.X0[k][1] *= mu; G.X0[k][2] *= mu; G.X12[k][1] = sp2(mu) * G.X12[k][1]; G.X12[k][2] = sp2(mu) * G.X12[k][2]; }
-  float lam0 = 0.f; f2 lam12 = sp2(0.f);
-  float c0 = vf[0] + bn; f2 c12 = mk2(vf[1], vf[2]);
-  const float m0 = limb == 0 ? 1.f : 0.f, m1 = limb == 1 ? 1.f : 0.f, m2 = limb == 2 ? 1.f : 0.f, m3 = limb == 3 ? 1.f : 0.f;
-  // sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first, which removes the
-  // ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
-  for (int it = 0; it < iters; it += 2) {
-    pgs_turn<0>(m0, G, lam0, lam12, c0, c12);
-    pgs_turn<1>(m1, G, lam0, lam12, c0, c12);
-    pgs_turn<2>(m2, G, lam0, lam12, c0, c12);
-    pgs_turn<3>(m3, G, lam0, lam12, c0, c12);
-    if (it + 1 < iters) {
-      pgs_turn<3>(m3, G, lam0, lam12, c0, c12);
-      pgs_turn<2>(m2, G, lam0, lam12, c0, c12);
-      pgs_turn<1>(m1, G, lam0, lam12, c0, c12);
-      pgs_turn<0>(m0, G, lam0, lam12, c0, c12);
+  S.lam0 = 0.f; S.lam12 = sp2(0.f);
+  S.c0 = vf[0] + bn; S.c12 = mk2(vf[1], vf[2]);
+  S.m0 = limb == 0 ? 1.f : 0.f; S.m1 = limb == 1 ? 1.f : 0.f; S.m2 = limb == 2 ? 1.f : 0.f; S.m3 = limb == 3 ? 1.f : 0.f;
+}
+// sweeps it0 (even) ... it1 - 1.  Sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first,
+// which removes the ordering bias an unconverged Gauss-Seidel solve would otherwise leave between the four limbs
+LM_DEV void pgs_sweeps(PgsState& S, int it0, int it1) {
+  for (int it = it0; it < it1; it += 2) {
+    pgs_turn<0>(S.m0, S.G, S.lam0, S.lam12, S.c0, S.c12);
+    pgs_turn<1>(S.m1, S.G, S.lam0, S.lam12, S.c0, S.c12);
+    pgs_turn<2>(S.m2, S.G, S.lam0, S.lam12, S.c0, S.c12);
+    pgs_turn<3>(S.m3, S.G, S.lam0, S.lam12, S.c0, S.c12);
+    if (it + 1 < it1) {
+      pgs_turn<3>(S.m3, S.G, S.lam0, S.lam12, S.c0, S.c12);
+      pgs_turn<2>(S.m2, S.G, S.lam0, S.lam12, S.c0, S.c12);
+      pgs_turn<1>(S.m1, S.G, S.lam0, S.lam12, S.c0, S.c12);
+      pgs_turn<0>(S.m0, S.G, S.lam0, S.lam12, S.c0, S.c12);
     }
   }
-  lam12 = sp2(mu) * lam12;
-  lam[0] = lam0; lam[1] = lam12.x; lam[2] = lam12.y;
-  // hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
+}
+// impulses found so far and the hub / plate velocity change  w = Phi sum_j T_j lam_j = sum_j B_j lam_j
+LM_DEV void pgs_finish(const PgsState& S, float mu, const R4 X[6], float lam[3], float w[6]) {
+  const f2 l12 = sp2(mu) * S.lam12;
+  lam[0] = S.lam0; lam[1] = l12.x; lam[2] = l12.y;
 #pragma unroll
-  for (int i = 0; i < 6; i++) { const f2 t = lam12 * X[i].q; w[i] = quad_sum(fmaf(lam0, X[i].p.y, t.x + t.y)); }
+  for (int i = 0; i < 6; i++) { const f2 t = l12 * X[i].q; w[i] = quad_sum(fmaf(S.lam0, X[i].p.y, t.x + t.y)); }
 }
 
 // free rigid body carried as (position, quaternion, body-coordinate spatial velocity about its origin)
@@ -689,19 +693,40 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     }
     float lam[3], w[6];
     LM_STAMP(3);
-    pgs_solve(P->pgs_iters, limb, P->mu, bn, vf, Wl, T, X, lam, w);
-    LM_STAMP(4);
-    // apply impulses
-    un = sv(v3(v0f[0] + w[0], v0f[1] + w[1], v0f[2] + w[2]), v3(v0f[3] + w[3], v0f[4] + w[4], v0f[5] + w[5]));
-#pragma unroll
-    for (int a = 0; a < 3; a++) qdn[a] = qdf[a] + JH[0][a] * lam[0] + JH[1][a] * lam[1] + JH[2][a] * lam[2];
-    if (MODE == 0) {
+    // PD-actuator families: the first pass looks for saturated drives after `sat_probe` sweeps (nearly every sub-step saturates a joint there and
+    // the pass only has to find out which; the velocity-drive tasks test after the full solve).  If nobody in the wavefront saturates, the same solve continues to
+    // pgs_iters - bit for bit the uninterrupted solve; otherwise every env is re-solved in pass 1 with its saturated set and the full count
+    // (an env without saturated joints repeats the unsaturated solve there: same result as continuing).
+    const int iters = P->pgs_iters;
+    constexpr bool PROBE = (VAR != 0);         // compiled into the PD-actuator families only: the velocity-drive step keeps its straight-line pass
+    const int n1 = (PROBE && pass == 0) ? min(P->sat_probe, iters) : iters;
+    PgsState S; pgs_setup(S, limb, P->mu, bn, vf, Wl, T, X);
+    pgs_sweeps(S, 0, n1);
+    bool continued = false;
+#define LM_FINISH_PASS { \
+      pgs_finish(S, P->mu, X, lam, w); \
+      un = sv(v3(v0f[0] + w[0], v0f[1] + w[1], v0f[2] + w[2]), v3(v0f[3] + w[3], v0f[4] + w[4], v0f[5] + w[5])); \
+      _Pragma("unroll") for (int a = 0; a < 3; a++) qdn[a] = qdf[a] + JH[0][a] * lam[0] + JH[1][a] * lam[1] + JH[2][a] * lam[2]; \
+      if (MODE == 0) { \
+        LM_WROW(0) LM_WROW(1) LM_WROW(2) LM_WROW(3) LM_WROW(4) LM_WROW(5) } }
 #define LM_WROW(I) { qdn[0] = fmaf(-comp<I>(K0), w[I], qdn[0]); qdn[1] = fmaf(-comp<I>(K1), w[I], qdn[1]); qdn[2] = fmaf(-comp<I>(K2), w[I], qdn[2]); }
-      LM_WROW(0) LM_WROW(1) LM_WROW(2) LM_WROW(3) LM_WROW(4) LM_WROW(5)
-#undef LM_WROW
+    LM_FINISH_PASS
+    LM_STAMP(4);
+    if (PROBE && pass == 0 && n1 < iters) {
+      // the probe (n1 < pgs_iters sweeps): does anybody in the wavefront saturate?
+      int any = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) { const float tau = kd * (tgt[a] - qdn[a]); any |= (tau > tmax[a] || tau < -tmax[a]) ? 1 : 0; }
+      if (!__any(quad_sum_i(any))) {           // no: the same solve continues to the full count (bit for bit the uninterrupted solve) and is final
+        pgs_sweeps(S, n1, iters);
+        LM_FINISH_PASS
+        continued = true;
+      }                                        // yes: the test below records the sets from the probe's velocities and pass 1 re-solves them
     }
+#undef LM_WROW
+#undef LM_FINISH_PASS
     if (pass == 0) {
-      if (effort) break;
+      if (effort || continued) break;          // (the one saturation test of a probed solve was the probe's)
       int any = 0;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -1767,6 +1792,8 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     const lm_params& p = params[t];
     if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
       return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
+    if (p.sat_probe < 0 || p.sat_probe > p.pgs_iters || (p.sat_probe & 1) || (p.sat_probe == 0 && p.pgs_iters > 0))
+      return fail(LM_EINVAL, "lm_create: sat_probe must be an even sweep count in [2, pgs_iters] (the sweeps alternate direction in pairs)");
     if (p.drive_mode < 0 || p.drive_mode > 2 || (p.drive_mode != 0 && p.variant != 0) || (p.drive_mode == LM_DRIVE_POSITION && !(p.kd > 0)))
       return fail(LM_EINVAL, "lm_create: drive_mode must be 0 (velocity), 1 (position: kd > 0) or 2 (effort), and 0 for the PD-actuator variants");
     if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || p.variant < 0 || p.variant > 2 ||
