@@ -314,7 +314,7 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // their mutual coupling enters at the contact's next turn), then its three impulse increments are quad-broadcast and every
 // lane updates c.  Identical arithmetic (up to rounding) to the oracle's sweep over the dense 12x12 system.
 // Row layout: row 0 (normal) in plain registers, rows 1 | 2 (friction) as one packed pair.
-struct PgsData { float nrW0; f2 W0t, nrWt; float X0[4][3]; f2 X12[4][3]; };   // own block: -1/W00, (W01 | W02), (-1/(mu W11) | -1/(mu W22)); columns 1, 2 of the X blocks carry mu;
+struct PgsData { f2 W0t, nrWt; float X0[4][3]; f2 X12[4][3]; };   // own block: (W01 | W02), (-1/(mu W11) | -1/(mu W22)); columns 1, 2 of the X blocks carry mu, row 0 (X0) is scaled by -1/W00 (the normal residual is carried as the unclamped impulse step);
                                                                                    // block towards contact K (K == own limb: the own block) by columns s: X0[K][s] = X[0][s], X12[K][s] = (X[1][s] | X[2][s])
 
 // ---- "four 6-vectors at once" layout of the pass linear algebra.  Component i of the vectors (v0, v1, v2, v3) is an R4: p = (v0[i] | v1[i]),
@@ -393,14 +393,15 @@ LM_DEV void pgs_cross_blocks(int limb, const R4 T[6], const R4 X[6], const float
 // execution mask (18 vector + 3 scalar instructions per turn) is 14 % SLOWER per sweep than selects (20 vector instructions).
 template <int K>
 LM_DEV void pgs_turn(float m, const PgsData& G, float& lam0, f2& lam12, float& c0, f2& c12) {
-  const float d0 = __builtin_amdgcn_fmed3f(c0 * G.nrW0, -lam0, __builtin_inff());      // max(-lam0, -c0 / W00) as one v_med3 (no canonicalising copy of -lam0)
+  const float d0 = __builtin_amdgcn_fmed3f(c0, -lam0, __builtin_inff());               // max(-lam0, -v_n / W00): c0 is carried as -v_n / W00 (one v_max, no canonicalising copy of -lam0)
   lam0 = fmaf(m, d0, lam0);                                                            // owner: the relaxed normal impulse, which bounds its friction rows
   const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
   const f2 d12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lam0, lam0), __builtin_amdgcn_fmed3f(u12.y, -lam0, lam0)) - lam12;
   lam12 = fma_(sp2(m), d12, lam12);
   const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d12.x), b2 = quad_bcast<K>(d12.y);
-  c0 = fmaf(G.X0[K][0], b0, fmaf(G.X0[K][1], b1, fmaf(G.X0[K][2], b2, c0)));
-  c12 = fma_(G.X12[K][0], sp2(b0), fma_(G.X12[K][1], sp2(b1), fma_(G.X12[K][2], sp2(b2), c12)));
+  // the normal increment's terms first: they are ready before the friction pair's broadcasts and fill those broadcasts' wait states
+  c0 = fmaf(G.X0[K][2], b2, fmaf(G.X0[K][1], b1, fmaf(G.X0[K][0], b0, c0)));
+  c12 = fma_(G.X12[K][2], sp2(b2), fma_(G.X12[K][1], sp2(b1), fma_(G.X12[K][0], sp2(b0), c12)));
 }
 
 // T[i].p.y, T[i].q = this lane's three contact rows (hub / plate wrench per unit impulse); X[i].p.y, X[i].q = B = Phi T
@@ -420,13 +421,13 @@ LM_DEV void pgs_setup(PgsState& S, int limb, float mu, float bn, const float vf[
   }
   // friction impulses are carried as lam_t / mu (bound = the normal impulse); mu = 0 pins them at zero
   const float imu = mu > 0.f ? 1.0f / mu : 0.f;
-  G.nrW0 = -1.0f / Wf[0]; G.W0t = mk2(Wf[1], Wf[2]); G.nrWt = mk2(-imu / Wf[3], -imu / Wf[5]);
+  const float nrW0 = -1.0f / Wf[0]; G.W0t = mk2(Wf[1], Wf[2]); G.nrWt = mk2(-imu / Wf[3], -imu / Wf[5]);
   pgs_cross_blocks<0>(limb, T, X, Wf, G.X0[0], G.X12[0]); pgs_cross_blocks<1>(limb, T, X, Wf, G.X0[1], G.X12[1]);
   pgs_cross_blocks<2>(limb, T, X, Wf, G.X0[2], G.X12[2]); pgs_cross_blocks<3>(limb, T, X, Wf, G.X0[3], G.X12[3]);
 #pragma unroll
-  for (int k = 0; k < 4; k++) { G.X0[k][1] *= mu; G.X0[k][2] *= mu; G.X12[k][1] = sp2(mu) * G.X12[k][1]; G.X12[k][2] = sp2(mu) * G.X12[k][2]; }
+  for (int k = 0; k < 4; k++) { G.X0[k][0] *= nrW0; G.X0[k][1] *= mu * nrW0; G.X0[k][2] *= mu * nrW0; G.X12[k][1] = sp2(mu) * G.X12[k][1]; G.X12[k][2] = sp2(mu) * G.X12[k][2]; }
   S.lam0 = 0.f; S.lam12 = sp2(0.f);
-  S.c0 = vf[0] + bn; S.c12 = mk2(vf[1], vf[2]);
+  S.c0 = (vf[0] + bn) * nrW0; S.c12 = mk2(vf[1], vf[2]);
   S.m0 = limb == 0 ? 1.f : 0.f; S.m1 = limb == 1 ? 1.f : 0.f; S.m2 = limb == 2 ? 1.f : 0.f; S.m3 = limb == 3 ? 1.f : 0.f;
 }
 // sweeps it0 (even) ... it1 - 1.  Sweeps alternate direction (contacts 0,1,2,3 then 3,2,1,0): no limb is systematically relaxed first,
