@@ -311,8 +311,8 @@ LM_DEV void limb_dynamics(const float* tl, const LimbKin& K, const float qd[3], 
 // Each lane keeps the current contact-space velocity c (3) of ITS contact, its own full 3x3 block, and the 3x3
 // cross blocks X_K = T_i^T B_K towards the other three contacts; lanes take turns, the lane whose turn it is
 // relaxes its normal row and then its two friction rows together (one packed update: both see the state the normal row left,
-// their mutual coupling enters at the contact's next turn), then its three impulse increments are quad-broadcast and every
-// lane updates c.  Identical arithmetic (up to rounding) to the oracle's sweep over the dense 12x12 system.
+// their mutual coupling enters at the contact's next turn; the pair is projected onto the friction cone), then its three impulse
+// increments are quad-broadcast and every lane updates c.  Identical arithmetic (up to rounding) to the oracle's sweep over the dense 12x12 system.
 // Row layout: row 0 (normal) in plain registers, rows 1 | 2 (friction) as one packed pair.
 struct PgsData { f2 W0t, nrWt; float X0[4][3]; f2 X12[4][3]; };   // own block: (W01 | W02), (-1/(mu W11) | -1/(mu W22)); columns 1, 2 of the X blocks carry mu, row 0 (X0) is scaled by -1/W00 (the normal residual is carried as the unclamped impulse step);
                                                                                    // block towards contact K (K == own limb: the own block) by columns s: X0[K][s] = X[0][s], X12[K][s] = (X[1][s] | X[2][s])
@@ -396,7 +396,10 @@ LM_DEV void pgs_turn(float m, const PgsData& G, float& lam0, f2& lam12, float& c
   const float d0 = __builtin_amdgcn_fmed3f(c0, -lam0, __builtin_inff());               // max(-lam0, -v_n / W00): c0 is carried as -v_n / W00 (one v_max, no canonicalising copy of -lam0)
   lam0 = fmaf(m, d0, lam0);                                                            // owner: the relaxed normal impulse, which bounds its friction rows
   const f2 u12 = fma_(fma_(G.W0t, sp2(d0), c12), G.nrWt, lam12);
-  const f2 d12 = mk2(__builtin_amdgcn_fmed3f(u12.x, -lam0, lam0), __builtin_amdgcn_fmed3f(u12.y, -lam0, lam0)) - lam12;
+  // projection of the friction pair onto the cone |lam_t| <= mu lam_n (here: |u| <= lam0, the pair being carried divided by mu): scale by
+  // min(1, lam0 / |u|).  |u| = 0 gives lam0 * inf = inf (or NaN when lam0 = 0 too), and v_min returns 1 for both
+  const float sc = fminf(1.0f, lam0 * __builtin_amdgcn_rsqf(fmaf(u12.x, u12.x, u12.y * u12.y)));
+  const f2 d12 = fma_(u12, sp2(sc), -lam12);
   lam12 = fma_(sp2(m), d12, lam12);
   const float b0 = quad_bcast<K>(d0), b1 = quad_bcast<K>(d12.x), b2 = quad_bcast<K>(d12.y);
   // the normal increment's terms first: they are ready before the friction pair's broadcasts and fill those broadcasts' wait states

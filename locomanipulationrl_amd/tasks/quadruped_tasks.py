@@ -16,7 +16,7 @@ from __future__ import annotations
 
 from typing import List, Optional
 
-from ..engine_config import MODE_LOCO, MODE_MANI, EngineParams
+from ..engine_config import FRICTION_SCALE, MODE_LOCO, MODE_MANI, EngineParams
 from ..robot.quadruped_robot import (QuadrupedRobotOVFixedBaseOmni, QuadrupedRobotOVOmni, QuadrupedRobotVerticalOVFixedOmni,
                                      QuadrupedRobotVerticalOVOmni)
 from .base.rl_task import CC_EXTRAS_KEYS, RLTask
@@ -79,6 +79,7 @@ class _QuadrupedTask(RLTask):
             mu = {"average": 0.5 * (mu_body + mu_g), "min": min(mu_body, mu_g), "max": max(mu_body, mu_g), "multiply": mu_body * mu_g}[comb]
         else:
             mu = mu_body
+        mu *= float(eng.get("friction_scale", FRICTION_SCALE))      # effective / nominal coefficient (engine_config.py, DESIGN.md 2.1: fitted, parity unpinned)
         rd = robot.robot_description
         if rd.control_mode not in ("velocity", "position", "effort"):          # robot.py:323-333
             raise AttributeError(f"Invalid control mode name {rd.control_mode!r}")
@@ -95,7 +96,7 @@ class _QuadrupedTask(RLTask):
         # `sim.engine.drive_limits_are_impulses: False` selects the 1.5 N m torque clamp.  The PD-actuator tasks clamp their torque in Python
         # (…custom_controller.py:289-307): a real 1.5 N m either way.
         mode = kw.get("mode", MODE_LOCO)
-        sweeps = eng.get("pgs_iters", {})          # contact sweeps per solve: {ground: 16, plate: 8}; a plain integer sets both
+        sweeps = eng.get("pgs_iters", {})          # contact sweeps per solve: {ground: 8, plate: 8}; a plain integer sets both
         if isinstance(sweeps, dict):
             sweeps = sweeps.get("ground" if mode == MODE_LOCO else "plate", -1)
         base = dict(

@@ -373,9 +373,14 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
       int r=3*i; real v=vf[r]+bn[i]; for (int c=0;c<12;c++) v+=W[r][c]*lam[c];
       real ln=lam[r]-v/W[r][r]; if (ln<0) ln=0; lam[r]=ln;
       /* the two friction rows of a contact relax together, both from the state the normal row left (one packed update in the kernel);
-         their mutual coupling W[t1][t2] enters at the contact's next turn */
+         their mutual coupling W[t1][t2] enters at the contact's next turn.  The pair is then projected onto the friction CONE
+         |lam_t| <= mu lam_n (isotropic Coulomb friction; DESIGN.md 2.1: the axis-aligned pyramid of rounds 1-2 made the replay outcomes depend
+         on the sweep count and missed PhysX's rows; lmo_params.pyramid = 1 keeps it for the evidence tables) */
       real vt[2]; for (int k=1;k<3;k++) { int rr=r+k; vt[k-1]=vf[rr]; for (int c=0;c<12;c++) vt[k-1]+=W[rr][c]*lam[c]; }
-      for (int k=1;k<3;k++) { int rr=r+k; real lt=lam[rr]-vt[k-1]/W[rr][rr]; real lim=mu*lam[r]; if (lt>lim) lt=lim; if (lt<-lim) lt=-lim; lam[rr]=lt; }
+      real l1=lam[r+1]-vt[0]/W[r+1][r+1], l2=lam[r+2]-vt[1]/W[r+2][r+2]; const real lim=mu*lam[r];
+      if (p->pyramid) { if (l1>lim) l1=lim; if (l1<-lim) l1=-lim; if (l2>lim) l2=lim; if (l2<-lim) l2=-lim; }
+      else { real n2=l1*l1+l2*l2; if (n2>lim*lim) { real sc=lim/sqrt(n2); l1*=sc; l2*=sc; } }
+      lam[r+1]=l1; lam[r+2]=l2;
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
     if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];

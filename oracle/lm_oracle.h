@@ -86,7 +86,7 @@ typedef struct {
   double max_depen_vel;      /* m/s cap on push-out */
   double max_joint_vel;      /* rad/s clamp on the driven joints' speed (USD maxJointVelocity 450 deg/s) */
   int32_t mode;              /* 0 = free base on ground (loco), 1 = fixed inverted base + plate (mani) */
-  int32_t pad0;
+  int32_t pyramid;           /* 0 (shipped): friction cone; 1: the axis-aligned friction pyramid of rounds 1-2 (evidence tables only; the kernel has no such switch) */
   double fixed_base_pos[3];
   double fixed_base_quat[4];
   double plate_mass;

@@ -41,7 +41,7 @@ class LmoParams(C.Structure):
         ("dt", C.c_double), ("substeps", C.c_int32), ("pgs_iters", C.c_int32), ("gravity", C.c_double),
         ("kd", C.c_double), ("tau_max", C.c_double), ("act_scale", C.c_double), ("mu", C.c_double),
         ("tip_radius", C.c_double), ("baumgarte", C.c_double), ("max_depen_vel", C.c_double), ("max_joint_vel", C.c_double),
-        ("mode", C.c_int32), ("pad0", C.c_int32),
+        ("mode", C.c_int32), ("pyramid", C.c_int32),
         ("fixed_base_pos", C.c_double * 3), ("fixed_base_quat", C.c_double * 4),
         ("plate_mass", C.c_double), ("plate_com", C.c_double * 3), ("plate_inertia", C.c_double * 3),
         ("plate_half", C.c_double * 3), ("plate_center", C.c_double * 3),
@@ -106,8 +106,8 @@ def make_model(rm) -> LmoModel:
 def make_params(ep) -> LmoParams:
     p = LmoParams()
     for name, ctype in LmoParams._fields_:
-        if name in ("pad0",):
-            continue
+        if name == "pyramid":
+            p.pyramid = int(getattr(ep, "pyramid", 0)); continue
         if name == "dr":
             for i, ch in enumerate(ep.dr):
                 p.dr[i].enabled, p.dr[i].operation, p.dr[i].distribution, p.dr[i].interval = int(ch.enabled), int(ch.operation), int(ch.distribution), int(ch.interval)

@@ -60,7 +60,7 @@ def replay(rec, step, servo=False, until_done=False):
     """step(action (12,)) -> (q (12,), obs (64,), reset flag, goal_reset flag, reward) advances one control step; the first call gets the
     zero action of VecEnvRLGames.reset().  servo=True steers the joints back onto the recording every step (actions still clipped to +-1).
     The replay stops on the engine's own reset flag or after the recording's last row (until_done: holds the last action's successor at
-    zero and keeps stepping up to 17 more rows - one streak length - to see a success streak that started late complete)."""
+    zero and keeps stepping up to 2 more rows to see a success streak that started a row or two late complete)."""
     T = rec.shape[0]
     q, obs, rst, _, rew = step(np.zeros(12))
     out = dict(T=T, row0_err=float(np.abs(q - rec[0]).max()), row0=q.copy(), rows=[q.copy()], rd=[rot_dist(obs)], rew=[rew], done_at=None, goal=0)
@@ -76,7 +76,7 @@ def replay(rec, step, servo=False, until_done=False):
             break
     out["rd_rec"] = np.array(out["rd"])                      # rot_dist over the recorded rows only
     if until_done and out["done_at"] is None:
-        for k in range(17):                                  # the recording is over: hold still (zero velocity targets) for at most one streak length
+        for k in range(2):                                   # the recording is over: hold still (zero velocity targets) for at most two more rows
             q, obs, rst, goal, rew = step(np.zeros(12))
             out["rd"].append(rot_dist(obs)); out["rew"].append(rew)
             if rst:

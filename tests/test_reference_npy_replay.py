@@ -10,21 +10,25 @@ What each group of assertions does and does not prove (the contract):
       the reference - and say nothing about gravity, contact or inertia (with gravity or friction switched off they are met even better;
       `test_joint_level_checks_are_a_drive_limit_test` keeps that on record).  Their negative control is the 1.5 N m torque clamp.
   ORIENTATION / TERMINATION CHECKS (the physics).  The base pose is not recorded; it is pinned through what the task computed from it:
-      PhysX's rot_dist entered the 0.15 rad success window on row T - 17 of each of the seven goal-known episodes and `test` ended in a
-      fall on its last row.  Asserted PER KIND: locomotion >= 3 of 4 files enter the window, manipulation 3 of 3, each within 6 rows of
-      PhysX; every file gets from >= 0.75 rad to <= 0.26 rad; no file terminates before PhysX did except by the knee test within 3 rows of
-      PhysX's entry; `test` terminates on its recorded last row.
-      NEGATIVE CONTROLS THAT MUST FAIL these checks: gravity 0, friction 0, one Gauss-Seidel sweep, a 20 mm foot, the 1.5 N m clamp.
+      PhysX's rot_dist entered the 0.15 rad success window on row T - 17 of each of the seven goal-known episodes, stayed inside for 17
+      rows, and `test` ended in a fall on its last row.  Asserted PER KIND: locomotion >= 3 of 4 files enter the window (the shipped
+      specification: 4 of 4), manipulation 3 of 3, each within 3 rows of PhysX; at least 85 of PhysX's 7 x 17 window rows are shared (97);
+      every file gets from >= 0.75 rad to <= 0.26 rad; no file terminates before PhysX did except by the knee test within 3 rows of PhysX's
+      entry; `test` terminates on its recorded last row.
+      NEGATIVE CONTROLS THAT MUST FAIL these checks: gravity 0, half gravity, friction 0, friction doubled, the axis-aligned friction
+      pyramid of rounds 1-2, the 1.5 N m torque clamp, a 20 mm foot (the last one only through the fall row of `test`: the recordings
+      hardly constrain the foot radius).
   EPISODE REWARD (north star: "joint states and episode reward").  PhysX's episode is 17 rows inside the window (rot reward
-      0.5 / (rot_dist + 0.1) >= 2.0 each, quadruped_pose_control.py:428-462) and the 600 bonus on the last row.  The replay, held still after
-      the recording's last row for at most one streak length, must end in success and collect a return inside the bracket PhysX's episode
-      implies, for >= 2 of 4 locomotion and >= 2 of 3 manipulation files (the bonus is 94 % of the return: missing it is a 94 % error).
+      0.5 / (rot_dist + 0.1) >= 2.0 each, quadruped_pose_control.py:428-462) and the 600 bonus on the last row.  The replay must end in
+      success within 2 rows of PhysX's last row (held still after the recording for that long at most) and collect a return inside the
+      bracket PhysX's episode implies, for >= 2 of 4 locomotion and >= 2 of 3 manipulation files (shipped: 3 + 2, three of them on PhysX's
+      very row; the bonus is 94 % of the return: missing it is a 94 % error).
   ROW 0 (one control period after reset, zero action).  PhysX's joints give way by 3e-3 ... 1.25e-2 rad (identical in every file); this
-      engine's by 1e-4 ... 3e-4 in the SAME direction on every joint.  The direction is asserted (a frozen robot fails it); the magnitude
-      is a documented residual (reproduced only by a drive that yields at ~1.5 N m, which the later rows rule out), bounded
-      here by the observed 4.2e-3 / 1.27e-2 so that it cannot grow unnoticed.
-The long-horizon outcome of a walking gait on four frictional point feet is chaotic: which individual files hold the goal changes with
-any perturbation of the contact model, so counts are asserted, never individual files.
+      engine's by 1e-4 ... 3e-4 in the SAME direction on every loaded joint.  The direction is asserted (a frozen robot fails it); the
+      magnitude is a documented residual (reproduced only by a drive that yields at ~1.5 N m, which the later rows rule
+      out), bounded here by the observed 4.2e-3 / 1.27e-2 so that it cannot grow unnoticed.
+  SOLVER INDEPENDENCE.  With the friction cone the outcomes do not depend on the number of Gauss-Seidel sweeps: 2, 8 (shipped) and 128
+      sweeps reach the same files on the same rows +- 1.
 """
 import numpy as np
 import pytest
@@ -90,12 +94,14 @@ def check_orientation(runs):
         r = runs[name]
         assert r["rd"][0] >= 0.75 and r["rd_rec"].min() <= 0.26, (name, r["rd"][0], r["rd_rec"].min())
         if r["first_succ"] is not None:
-            assert abs(r["first_succ"] - r["succ_row"]) <= 6, (name, r["first_succ"], r["succ_row"])
+            assert abs(r["first_succ"] - r["succ_row"]) <= 3, (name, r["first_succ"], r["succ_row"])
         if r["done_at"] is not None and r["done_at"] < r["T"] - 1:
             assert r["done_at"] >= r["succ_row"] - 3, (name, r["done_at"])
     n = reached_by_kind(runs)
     assert n["loco"][0] >= 3 and n["loco"][1] == 4, n
     assert n["mani"][0] == 3 and n["mani"][1] == 3, n
+    shared = sum(runs[name]["in_window"] for name in R.GOAL_KNOWN)
+    assert shared >= 85, shared                                   # of PhysX's 7 x 17 rows inside the success window
 
 
 def orientation_ok(runs):
@@ -135,7 +141,7 @@ def check_episode_reward(runs_until_done):
         r = runs_until_done[name]; e = episode_reward(r)
         print(f"{name:30s} return over PhysX's window rows + bonus {e['ret']:7.1f}  bracket [{e['lo']:.1f}, {e['hi']:.1f}]  bonus on row {e['bonus_row']} (PhysX {r['T'] - 1})")
         if e["ok"]:
-            assert e["bonus_row"] - (r["T"] - 1) <= 17, name             # within one streak length of PhysX's last row
+            assert 0 <= e["bonus_row"] - (r["T"] - 1) <= 2, name            # on PhysX's last row or at most two rows later
             ok[R.kind_of(name)] += 1
     assert ok["loco"] >= 2 and ok["mani"] >= 2, ok
 
@@ -151,7 +157,9 @@ def test_episode_reward_of_the_replays(robot_model, recordings):
     check_episode_reward(run_all(robot_model, recordings, files=R.GOAL_KNOWN, until_done=True))
 
 
-@pytest.mark.parametrize("label, kw", [("gravity 0", dict(gravity=0.0)), ("friction 0", dict(mu=0.0)), ("one Gauss-Seidel sweep", dict(pgs_iters=1)),
+@pytest.mark.parametrize("label, kw", [("gravity 0", dict(gravity=0.0)), ("half gravity", dict(gravity=4.905)), ("friction 0", dict(mu=0.0)),
+                                       ("friction doubled", dict(mu=1.6)), ("friction pyramid of rounds 1-2 (8 sweeps, mu 1.0)", dict(pyramid=1, mu=1.0)),
+                                       ("friction pyramid, 16 sweeps", dict(pyramid=1, mu=1.0, pgs_iters=16)),
                                        ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5))])
 def test_negative_controls_fail_the_orientation_checks(robot_model, recordings, label, kw):
     """A broken simulator must not pass: each of these is rejected by the orientation / termination checks."""
@@ -169,7 +177,7 @@ def test_joint_level_checks_are_a_drive_limit_test(robot_model, recordings):
     tr, early = [], []
     for r in run_all(robot_model, recordings, tau_max=1.5).values():
         tr.append(r["tracked"]); early.append(r["early"])
-    assert np.mean(tr) < 0.80 and np.mean(early) > 0.05, (np.mean(tr), np.mean(early))
+    assert np.mean(tr) < 0.80 and np.mean(early) > 0.02, (np.mean(tr), np.mean(early))          # shipped: 0.98 and 0.003
 
 
 def test_servo_replay_keeps_the_joints_on_the_recording(robot_model, recordings):
@@ -180,16 +188,18 @@ def test_servo_replay_keeps_the_joints_on_the_recording(robot_model, recordings)
         assert r["qerr"] <= 0.05 and np.abs(r["rows"] - recordings[name][:len(r["rows"])]).mean() < 2e-3, (name, r["qerr"])
 
 
-def test_sweep_count_is_in_the_converged_plateau(robot_model, recordings):
-    """The shipped sweep counts (16 on the ground, 8 on the plate) give the orientation outcomes of eight times as many sweeps: the same
-    goal-known files reach the window, entering within one row of each other.  (The row on which `test` falls is not on a plateau: 22 for
-    14 ... 20 and 26 ... 40 sweeps, later for 22, 24, 64 and 128; DESIGN.md 2.1 prints the table.)"""
-    a = run_all(robot_model, recordings, files=R.GOAL_KNOWN)
-    b = run_all(robot_model, recordings, files=R.GOAL_KNOWN, pgs_iters=128)
-    for name in a:
-        assert (a[name]["first_succ"] is None) == (b[name]["first_succ"] is None), name
-        if a[name]["first_succ"] is not None:
-            assert abs(a[name]["first_succ"] - b[name]["first_succ"]) <= 1, name
+def test_outcome_does_not_depend_on_the_sweep_count(robot_model, recordings):
+    """With the friction cone the orientation outcomes are those of the converged contact solve at any sweep count: 2, 8 (shipped) and 128
+    sweeps reach the same goal-known files, entering within one row of each other, and `test` falls on the same row.  (With the
+    axis-aligned friction pyramid of rounds 1-2 which files entered changed from one count to the next)"""
+    a = run_all(robot_model, recordings, files=R.GOAL_KNOWN + ["test"])
+    for other in (2, 128):
+        b = run_all(robot_model, recordings, files=R.GOAL_KNOWN + ["test"], pgs_iters=other)
+        for name in R.GOAL_KNOWN:
+            assert (a[name]["first_succ"] is None) == (b[name]["first_succ"] is None), (other, name)
+            if a[name]["first_succ"] is not None:
+                assert abs(a[name]["first_succ"] - b[name]["first_succ"]) <= 1, (other, name)
+        assert a["test"]["done_at"] == b["test"]["done_at"], other
 
 
 # ---------------------------------------------------------------------------------------------------------------- HIP engine
