@@ -46,8 +46,10 @@ def test_config3_manipulation_4096():
             s = task.engine.state
             assert (s[40:44].norm(dim=0) - 1).abs().max() < 1e-5                                # plate quaternion
             # the plate stays near the inverted robot: an env whose plate slides off or is thrown resets (plate-frame height tests,
-            # quadruped_manipulate_plate.py:576-603) before it can leave this box
-            assert float(s[37:39].abs().max()) < 0.6 and float(s[39].min()) > -0.05 and float(s[39].max()) < 0.6
+            # quadruped_manipulate_plate.py:576-603) before it can leave this box.  Lower z bound = a plate's half-width below the base plane
+            # (z 0): the resets are written in the PLATE frame, so a tilted plate sliding past the frame edge can be centimetres below the base
+            # plane for the few steps until the corner / knee test fires (-0.059 seen with round 3's friction cone; same reason as config 4's bound)
+            assert float(s[37:39].abs().max()) < 0.6 and float(s[39].min()) > -0.25 and float(s[39].max()) < 0.6
             assert float(s[44:50].abs().max()) < 50.0
             assert (task.plate_pos_ground - s[37:40].T).abs().max() == 0                        # the reference-named views are the engine's memory
     assert total > 0
