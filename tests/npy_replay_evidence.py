@@ -7,7 +7,9 @@ readings, foot geometries and depenetration rules.
 
 Tables
   sweeps      per kind (locomotion 4 goal-known files / manipulation 3): files entering PhysX's 0.15 rad success window, their entry rows
-              against PhysX's, rows inside PhysX's window, the row on which `test` ends (PhysX 22) - for 8 ... 128 sweeps at mu 1.0 and 0.7
+              against PhysX's, rows inside PhysX's window, the row on which `test` ends (PhysX 22) - for 1 ... 128 sweeps, friction cone
+              (shipped) and the axis-aligned pyramid of rounds 1-2
+  friction    the same against the friction coefficient (cone)
   controls    the negative controls of tests/test_reference_npy_replay.py and the round-1 / round-2 specifications
   drive       joint-level statistics (tracked = share of joint-steps whose displacement matches the recording to 1e-3 rad; early = mean
               |displacement error| over the first 4 steps in units of a full-scale step; qerr = worst joint deviation) for readings of
@@ -57,18 +59,27 @@ def main():
     rm = load_model("quadruped_robot_v2"); rec = R.load(); dt = 0.0083
     doc = {"source": "tests/npy_replay_evidence.py (CPU oracle fp64, open-loop replay of tests/golden/npy_traj.npz)"}
     G = R.GOAL_KNOWN + ["test"]
-    print("== sweeps x friction (per kind)")
+    def shared(o):
+        return sum(o["loco"]["rows_in_physx_window"]) + sum(o["mani"]["rows_in_physx_window"])
+    print("== friction model x sweeps (per kind; shared = rows inside PhysX's success windows, of 119)")
     doc["sweeps"] = []
-    for mu in (1.0, 0.7):
-        for it in (8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 40, 64, 128):
-            o = outcome(run(rm, rec, G, pgs_iters=it, mu=mu)); o.update(pgs_iters=it, mu=mu); doc["sweeps"].append(o)
-            print(f"mu {mu} sweeps {it:3d}: {fmt(o)}", flush=True)
+    for label, base in (("cone, mu 0.8 (shipped)", dict()), ("cone, mu 1.0 (nominal)", dict(mu=1.0)), ("pyramid, mu 1.0 (rounds 1-2)", dict(pyramid=1, mu=1.0)), ("pyramid, mu 0.7", dict(pyramid=1, mu=0.7))):
+        for it in (1, 2, 4, 8, 12, 16, 24, 32, 64, 128):
+            o = outcome(run(rm, rec, G, pgs_iters=it, **base)); o.update(model=label, pgs_iters=it, shared=shared(o)); doc["sweeps"].append(o)
+            print(f"{label:30s} sweeps {it:3d}: {fmt(o)} | shared {o['shared']}", flush=True)
+    print("== friction coefficient (cone, 8 and 64 sweeps)")
+    doc["friction"] = []
+    for mu in (0.5, 0.6, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0, 1.1, 1.2):
+        for it in (8, 64):
+            o = outcome(run(rm, rec, G, pgs_iters=it, mu=mu)); o.update(mu=mu, pgs_iters=it, shared=shared(o)); doc["friction"].append(o)
+            print(f"cone mu {mu:4.2f} sweeps {it:3d}: {fmt(o)} | shared {o['shared']}", flush=True)
     print("== negative controls and earlier specifications")
     doc["controls"] = []
-    for label, kw in [("shipped specification", {}), ("gravity 0", dict(gravity=0.0)), ("friction 0", dict(mu=0.0)), ("one sweep", dict(pgs_iters=1)),
-                      ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5)), ("round 2: 8 sweeps on the ground", dict(pgs_iters=8))]:
-        runs = run(rm, rec, **kw); o = outcome(runs); o.update(variant=label, joints=joint_stats(runs)); doc["controls"].append(o)
-        print(f"{label:32s} {fmt(o)}  joints {o['joints']}", flush=True)
+    for label, kw in [("shipped specification", {}), ("gravity 0", dict(gravity=0.0)), ("half gravity", dict(gravity=4.905)), ("friction 0", dict(mu=0.0)), ("friction doubled", dict(mu=1.6)),
+                      ("friction pyramid of rounds 1-2 (8 sweeps, mu 1.0)", dict(pyramid=1, mu=1.0)), ("friction pyramid, 16 sweeps", dict(pyramid=1, mu=1.0, pgs_iters=16)),
+                      ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5))]:
+        runs = run(rm, rec, **kw); o = outcome(runs); o.update(variant=label, joints=joint_stats(runs), shared=shared(o)); doc["controls"].append(o)
+        print(f"{label:50s} {fmt(o)} | shared {o['shared']}  joints {o['joints']}", flush=True)
     print("== readings of set_max_efforts(1.5): the joint-level statistics")
     doc["drive"] = []
     for label, kw in [("1.5 N m torque clamp", dict(tau_max=1.5)), ("2.0 N m (the USD's maxForce)", dict(tau_max=2.0)), ("3 N m", dict(tau_max=3.0)), ("6 N m", dict(tau_max=6.0)),
@@ -94,7 +105,7 @@ def main():
                              physx_deflection=[round(float(x), 5) for x in (rec[name][0] - init)])
         doc["row0"].append(row)
         print(f"{label:66s} ground {row['ground']['err']:.4f}  plate {row['plate']['err']:.4f}", flush=True)
-    print("== per file (shipped specification; replays held still for up to 17 rows after the recording to let a late streak complete)")
+    print("== per file (shipped specification; replays held still for up to 2 rows after the recording to let a late streak complete)")
     doc["files"] = []
     runs = run(rm, rec, until_done=False); held = run(rm, rec, R.GOAL_KNOWN, until_done=True)
     for name in R.FILES:
