@@ -13,13 +13,15 @@
  *     robot/base/robot.py:276-321 (state read-back), :444-461 (take_action);
  *     utils/math.py:33-193.  PINNED by golden vectors generated from the reference's
  *     own Python (tests/golden/task_*.npz, tools/gen_golden.py).
- *   - physics (reference row a7 = closed-source PhysX, absent from /root/reference):
- *     PARITY UNPINNED against PhysX.  The oracle is a float64 restatement of this
- *     repo's own physics specification written with a
- *     deliberately different algorithm from the HIP kernel (dense Jacobian
- *     projection + Cholesky instead of limb-aggregate articulated-body sweeps),
- *     pinned only by the weak facts of SURVEY 8(c): FK known answer, loop closure,
- *     mass, .npy row 0 envelope, analytic cases.
+ *   - physics (reference row a7 = closed-source PhysX, absent from /root/reference): a float64 restatement of this repo's own physics
+ *     specification written with a deliberately different algorithm from the HIP kernel (dense Jacobian
+ *     projection + Cholesky + dense Delassus matrix instead of limb-aggregate articulated-body sweeps).  PhysX itself cannot be run or
+ *     read; what pins the SPECIFICATION to it: the FK known answer, loop closure, mass, analytic cases and - the only
+ *     simulator-derived numbers the reference holds - its 13 recorded PhysX joint trajectories, replayed open loop
+ *     (tests/test_reference_npy_replay.py, DESIGN.md 2.1: per-kind entry rows into PhysX's success windows, shared window rows, the fall
+ *     row, episode reward, negative controls).  PARITY UNPINNED and labelled so: the reading of the drive limit (tau_max), the effective
+ *     friction coefficient (0.8 x nominal, fitted), row 0's deflection magnitude, the physics attributes of the domain
+ *     randomisation.
  *
  * Build:  make -C oracle   (gcc -O2 -shared; -DLMO_FLOAT for the fp32 variant)
  */
