@@ -80,7 +80,7 @@ def test_ground_reaction_balances_weight(robot_model):
         fn = lam[0::3].sum() / ep.dt
         assert abs(fn - total * ep.gravity) < 0.03 * total * ep.gravity, (fn, total * ep.gravity)
         assert (lam[0::3] > 0).all()                                                    # all four tips carry load
-        assert np.abs(lam[1::3]).max() <= ep.mu * lam[0::3].max() + 1e-12              # friction inside the pyramid
+        assert (np.hypot(lam[1::3], lam[2::3]) <= ep.mu * lam[0::3] + 1e-12).all()     # every contact's friction impulse inside its cone
 
 
 def test_plate_rests_on_inverted_robot(robot_model):
