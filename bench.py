@@ -289,7 +289,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if backend == "nccl" else "synthetic (REHEARSAL over gloo, ranks share GPUs: not a measurement)",
             "config": {"workload": "QuadrupedPoseControl (horizontal locomotion), 4096 envs per GPU, actions U(-1,1) fresh each step, "
-                                   "dt 0.0083 x 4 sub-steps, 16 PGS sweeps, obs 64 / states 93",
+                                   "dt 0.0083 x 4 sub-steps, 8 PGS sweeps with cone friction, obs 64 / states 93",
                        "envs_per_gpu": N, "global_envs": world * N, "physics_substeps_per_s": value * 4,
                        # `value` divides by the wall clock around the timed region INCLUDING its closing barrier + synchronize (at 20 steps that
                        # tail is a fifth of the window); the same region by the HIP events on the launch stream, rank 0:
