@@ -288,3 +288,28 @@ def test_position_and_effort_control_modes_through_the_wrapper():
         if dm == 1:
             with pytest.raises(NotImplementedError):
                 env._task.pre_physics_step(torch.zeros(16, 12))
+
+
+def test_contact_and_drive_parameters_reach_the_engine_block():
+    """The physics parameters chosen on the reference's recordings travel from the task YAML into the parameter blocks: friction =
+    0.8 x the combined nominal coefficient on both surfaces, 8 contact sweeps, the drive limit read as an impulse per step (max_effort / dt),
+    the PD families' real 1.5 N m clamp with their 4-sweep saturation probe - and the YAML switches that override them."""
+    from locomanipulationrl_amd.utils.config import SimConfig, load_config
+    from locomanipulationrl_amd.utils.task_util import task_map
+
+    def blocks(name, **eng):
+        cfg = load_config(name, num_envs=32)
+        cfg["task"]["sim"].setdefault("engine", {}).update(eng)
+        return task_map()[name](name=name, sim_config=SimConfig(cfg), env=None).engine_params()
+
+    lo, ma = blocks("JointLocomanipulation")
+    assert lo.mode == 0 and ma.mode == 1 and abs(lo.mu - 0.8) < 1e-12 and abs(ma.mu - 0.8) < 1e-12 and lo.pgs_iters == 8 and ma.pgs_iters == 8
+    assert abs(lo.tau_max - 1.5 / 0.0083) < 1e-9 and lo.sat_probe == lo.pgs_iters and lo.variant == 0
+    (single,) = blocks("QuadrupedPoseControl")                       # material 2.0 averaged with the ground plane's 0.0 (rl_task.py:130), times 0.8
+    assert abs(single.mu - 0.8) < 1e-12
+    (clamp,) = blocks("QuadrupedPoseControl", drive_limits_are_impulses=False, friction_scale=1.0, pgs_iters=12)
+    assert clamp.tau_max == 1.5 and abs(clamp.mu - 1.0) < 1e-12 and clamp.pgs_iters == 12
+    (cc,) = blocks("QuadrupedPoseControlCustomController")
+    assert cc.variant == 1 and cc.tau_max == 1.5 and cc.sat_probe == 4 and cc.pgs_iters == 8 and abs(cc.dt - 0.005) < 1e-12
+    lo2, ma2 = blocks("JointLocomanipulationPositionControl", pgs_iters={"ground": 10, "plate": 6})
+    assert (lo2.pgs_iters, ma2.pgs_iters, lo2.sat_probe, ma2.sat_probe) == (10, 6, 4, 4)
