@@ -17,6 +17,7 @@ Tables
   row0        one control period after reset under zero action: max |q - recording| per kind for drive limit x depenetration rule; the
               recorded deflection (4.2e-3 rad on the ground, 1.27e-2 rad under the plate) against this engine's
   files       the per-file outcome of the shipped specification
+  link_clearance   how close the (unmodelled) link hulls come to the ground / the plate before a reset fires
 """
 import json
 import os
@@ -115,6 +116,25 @@ def main():
                    rows_in_physx_window=r["in_window"] if name in R.GOAL_KNOWN else None, closest=round(float(r["rd_rec"].min()), 3), last=round(float(r["rd_rec"][-1]), 3),
                    success_row_when_held=(h["done_at"] if (h and h["goal"]) else None), return_when_held=(round(float(h["rew"].sum()), 1) if h else None))
         doc["files"].append(row); print(row, flush=True)
+    print("== link colliders (Design/Scripts/setup_collisions.py:3-10 keeps the link hulls): lowest knee origin above its contact surface before any reset")
+    from oracle.lmo import Oracle
+    doc["link_clearance"] = []
+    for name in R.FILES:
+        kind = R.kind_of(name); o = Oracle(rm, R.cotrain_params(kind)); phys, task, cnt = o.new_state(1); low = 1e9
+        for a in np.vstack([np.zeros((1, 12)), R.recovered_actions(rec[name])]):
+            o.step(phys, task, cnt, a[None], seed=0)
+            if cnt[0, 3]:
+                break
+            knees = o.fk(phys)[1][0]
+            if kind == "loco":
+                h = knees[:, 2]
+            else:                      # distance from the nearer face of the plate's slab, plate coordinates
+                w, x, y, z = phys[0, 40:44]
+                Rp = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                               [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+                h = np.abs(((knees - phys[0, 37:40]) @ Rp)[:, 2] - 0.004) - 0.004
+            low = min(low, float(h.min()))
+        row = dict(file=name, lowest_knee_origin_mm=round(low * 1e3, 1), link_hull_clearance_mm=round(low * 1e3 - 12.5, 1)); doc["link_clearance"].append(row); print(row, flush=True)
     if len(sys.argv) > 1:
         json.dump(doc, open(sys.argv[1], "w"), indent=1)
 
