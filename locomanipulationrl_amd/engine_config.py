@@ -20,8 +20,9 @@ trajectories (tests/golden/npy_traj.npz; tests/npy_replay
       reversals within one control period, which a 1.5 N m torque clamp on this 2.26 kg robot cannot do in this engine (section 2.1's
       negative control); the drive limit is therefore read as PhysX's per-step IMPULSE limit (1.5 N m s per 0.0083 s step = 180.7 N m,
       never binding).  Whether the reference's Isaac build raised PxArticulationFlag::eDRIVE_LIMITS_ARE_FORCES cannot be checked here,
-      and row 0 of the same recordings (the joints give way by 3e-3 ... 1.25e-2 rad while the scene settles) is reproduced only by a
-      drive that yields at about 1.5 N m - no single reading fits both, see DESIGN.md 2.2.  `drive_limits_are_impulses=False` selects
+      and row 0 of the same recordings (the joints give way by 3e-3 ... 1.25e-2 rad while the scene settles) shows what the limit really is:
+      an impulse limit of 1.5 N m x dt PER SOLVER ITERATION (16 per step), which binds only on loads that arrive inside one iteration - the
+      plate scene's start-in-penetration - and amounts to 24 N m on sustained ones (reproduced in a sub-iterated oracle run).  `drive_limits_are_impulses=False` selects
       the torque reading; bench.py reports the headline under both.
   friction CONE, mu = 0.8 x the nominal coefficient, pgs_iters 8 (round 3): with the axis-aligned friction pyramid of rounds 1-2 the replay's
       orientation outcomes depended on the sweep count (1 of 4 locomotion files entered PhysX's success window at 8 sweeps, 3 of 4 from 12 on)
