@@ -194,7 +194,7 @@ def test_row0_mechanism_is_the_per_iteration_drive_clamp(robot_model, recordings
     (max effort 1.5 x dt each).  Emulated in the oracle by splitting the step into K sub-steps with that impulse limit each, uncapped
     depenetration (the reference's max_depenetration_velocity 100): K = 16 - the reference's own solver_position_iteration_count - lands on
     PhysX's deflection (0.0124 rad on the saturating joints against 0.0125; 8 of 12 joints to 1e-3 rad), K = 8 / 32 / 64 give 0.016 / 0.006 /
-    0.004.  No parameter is fitted.  (The shipped engine does not sub-iterate: this is the documented residual of row 0, not its cure.)"""
+    0.004.  The plateau is the USD's joint speed limit (450 deg/s) held for three iterations: halving the limit halves it.  No parameter is fitted.  (The shipped engine does not sub-iterate: this is the documented residual of row 0, not its cure.)"""
     init = np.array(R.INIT_Q); ref = recordings["mlp_joint_mani"][0] - init
     defl = {}
     for K in (8, 16, 32):
@@ -203,6 +203,8 @@ def test_row0_mechanism_is_the_per_iteration_drive_clamp(robot_model, recordings
     assert np.abs(defl[16] - ref).max() < 3.5e-3 and (np.abs(defl[16] - ref) < 1e-3).sum() >= 7, defl[16]
     assert (np.sign(defl[16]) == np.sign(ref)).all()
     assert abs(np.abs(defl[16]).max() - 0.0125) < 5e-4 and np.abs(defl[8]).max() > 0.015 and np.abs(defl[32]).max() < 0.008, {k: np.abs(v).max() for k, v in defl.items()}
+    half = R.cotrain_params("mani", dt=0.0083 / 16, substeps=64, tau_max=24.0, baumgarte=1.0, max_depen_vel=100.0, max_joint_vel=3.927)
+    assert abs(np.abs(R.oracle_stepper(robot_model, half)(np.zeros(12))[0] - init).max() - 0.0062) < 5e-4
 
 
 def test_04roll_recording_under_its_identified_goal(robot_model, recordings):
