@@ -45,7 +45,7 @@ extern "C" {
  * caller's sizeof(lm_params) and LM_TABLE_FLOATS (first three fields); lm_create returns LM_EINVAL when any of them differs from what the
  * library was built with, instead of reading a shifted struct or past the end of a shorter table.
  *   1  round 1     2  round 2 (drive_mode, 502-float table; not stamped)     3  round 3 (the stamp itself; pgs_iters per contact surface) */
-#define LM_ABI_VERSION 3
+#define LM_ABI_VERSION 4
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
  * sources in the reference are cited there. */
@@ -105,9 +105,6 @@ typedef struct lm_params {
                                 LM_DRIVE_VELOCITY  target = a * act_scale [rad/s]           implicit damper kd (the mode every task of the path uses)
                                 LM_DRIVE_POSITION  target = a * act_scale [rad] (act_scale = pi); tau = pd_kp (q* - q) - kd qd, re-evaluated per sub-step
                                 LM_DRIVE_EFFORT    tau = a * act_scale [N m] (act_scale = torque limit), gains off */
-  int32_t sat_probe;         /* variants 1 / 2: contact sweeps of the first drive pass after which drive saturation is tested (even, 2 ... pgs_iters;
-                                pgs_iters = after the full solve, which is what variant 0 always does).  Envs without a saturated joint continue the same solve to pgs_iters; the others are re-solved with their
-                                saturated joints at the constant limit torque and the full count.  DESIGN.md 3.3 */
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */

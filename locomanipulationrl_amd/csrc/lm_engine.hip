@@ -585,6 +585,20 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   // effort mode (RobotOmni.take_action, robot.py:455-459): tgt IS the joint torque, gains off = the constant-torque branch from the start
   const bool effort = (VAR == 0) && P->drive_mode == LM_DRIVE_EFFORT;
   bool sat[3] = {effort, effort, effort}; float tsat[3] = {effort ? tgt[0] : 0.f, effort ? tgt[1] : 0.f, effort ? tgt[2] : 0.f};
+  // PD-actuator families: the reference evaluates  clamp(kp (q* - q) - kd qd, +-max_effort)  on the state BEFORE the sub-step and holds it
+  // (quadruped_pose_control_custom_controller.py:289-293), so which joints sit on the limit is known up front: those get the constant limit
+  // torque from the first pass on, the others the implicit form of the same PD law.  The test after the solve then only catches the few
+  // unsaturated joints whose implicit (end-of-step) torque left the limit - 0.2 % of the joint-sub-steps under random actions, so the second
+  // pass runs in about a tenth of the wavefront-sub-steps instead of all of them - and the applied torque never exceeds max_effort.
+  // (Variant 0 with a finite tau_max limits the force of an implicit drive, which only the solve can tell.)
+  if (VAR) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float tau = kd * (tgt[a] - qd[a]);
+      const bool hi_ = tau > tmax[a], lo_ = tau < -tmax[a];
+      sat[a] = hi_ || lo_; tsat[a] = hi_ ? tmax[a] : -tmax[a];
+    }
+  }
   float qdn[3]; SV un;
   for (int pass = 0; pass < 2; pass++) {
     asm volatile("" ::: "memory");          // keep the stash reloads inside the pass (no hoisting across the PGS loop)
@@ -697,46 +711,31 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     }
     float lam[3], w[6];
     LM_STAMP(3);
-    // PD-actuator families: the first pass looks for saturated drives after `sat_probe` sweeps (nearly every sub-step saturates a joint there and
-    // the pass only has to find out which; the velocity-drive tasks test after the full solve).  If nobody in the wavefront saturates, the same solve continues to
-    // pgs_iters - bit for bit the uninterrupted solve; otherwise every env is re-solved in pass 1 with its saturated set and the full count
-    // (an env without saturated joints repeats the unsaturated solve there: same result as continuing).
-    const int iters = P->pgs_iters;
-    constexpr bool PROBE = (VAR != 0);         // compiled into the PD-actuator families only: the velocity-drive step keeps its straight-line pass
-    const int n1 = (PROBE && pass == 0) ? min(P->sat_probe, iters) : iters;
     PgsState S; pgs_setup(S, limb, P->mu, bn, vf, Wl, T, X);
-    pgs_sweeps(S, 0, n1);
-    bool continued = false;
-#define LM_FINISH_PASS { \
-      pgs_finish(S, P->mu, X, lam, w); \
-      un = sv(v3(v0f[0] + w[0], v0f[1] + w[1], v0f[2] + w[2]), v3(v0f[3] + w[3], v0f[4] + w[4], v0f[5] + w[5])); \
-      _Pragma("unroll") for (int a = 0; a < 3; a++) qdn[a] = qdf[a] + JH[0][a] * lam[0] + JH[1][a] * lam[1] + JH[2][a] * lam[2]; \
-      if (MODE == 0) { \
-        LM_WROW(0) LM_WROW(1) LM_WROW(2) LM_WROW(3) LM_WROW(4) LM_WROW(5) } }
-#define LM_WROW(I) { qdn[0] = fmaf(-comp<I>(K0), w[I], qdn[0]); qdn[1] = fmaf(-comp<I>(K1), w[I], qdn[1]); qdn[2] = fmaf(-comp<I>(K2), w[I], qdn[2]); }
-    LM_FINISH_PASS
-    LM_STAMP(4);
-    if (PROBE && pass == 0 && n1 < iters) {
-      // the probe (n1 < pgs_iters sweeps): does anybody in the wavefront saturate?
-      int any = 0;
+    pgs_sweeps(S, 0, P->pgs_iters);
+    pgs_finish(S, P->mu, X, lam, w);
+    un = sv(v3(v0f[0] + w[0], v0f[1] + w[1], v0f[2] + w[2]), v3(v0f[3] + w[3], v0f[4] + w[4], v0f[5] + w[5]));
 #pragma unroll
-      for (int a = 0; a < 3; a++) { const float tau = kd * (tgt[a] - qdn[a]); any |= (tau > tmax[a] || tau < -tmax[a]) ? 1 : 0; }
-      if (!__any(quad_sum_i(any))) {           // no: the same solve continues to the full count (bit for bit the uninterrupted solve) and is final
-        pgs_sweeps(S, n1, iters);
-        LM_FINISH_PASS
-        continued = true;
-      }                                        // yes: the test below records the sets from the probe's velocities and pass 1 re-solves them
-    }
+    for (int a = 0; a < 3; a++) qdn[a] = qdf[a] + JH[0][a] * lam[0] + JH[1][a] * lam[1] + JH[2][a] * lam[2];
+    if (MODE == 0) {
+#define LM_WROW(I) { qdn[0] = fmaf(-comp<I>(K0), w[I], qdn[0]); qdn[1] = fmaf(-comp<I>(K1), w[I], qdn[1]); qdn[2] = fmaf(-comp<I>(K2), w[I], qdn[2]); }
+      LM_WROW(0) LM_WROW(1) LM_WROW(2) LM_WROW(3) LM_WROW(4) LM_WROW(5)
 #undef LM_WROW
-#undef LM_FINISH_PASS
+    }
+    LM_STAMP(4);
     if (pass == 0) {
-      if (effort || continued) break;          // (the one saturation test of a probed solve was the probe's)
+      if (effort) break;
       int any = 0;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const float tau = kd * (tgt[a] - qdn[a]);
         const bool hi_ = tau > tmax[a], lo_ = tau < -tmax[a];
-        sat[a] = hi_ || lo_; tsat[a] = hi_ ? tmax[a] : -tmax[a]; any |= (hi_ || lo_) ? 1 : 0;
+        if (VAR) {                             // joints already on the limit (the pre-step decision) stay there
+          const bool nw = !sat[a] && (hi_ || lo_);
+          tsat[a] = nw ? (hi_ ? tmax[a] : -tmax[a]) : tsat[a]; sat[a] = sat[a] || nw; any |= nw ? 1 : 0;
+        } else {
+          sat[a] = hi_ || lo_; tsat[a] = hi_ ? tmax[a] : -tmax[a]; any |= (hi_ || lo_) ? 1 : 0;
+        }
       }
       any = quad_sum_i(any);
       if (!__any(any)) break;                  // wave-uniform: nobody saturated
@@ -1777,7 +1776,7 @@ static void derive_params(lm_params* p) {
 extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
-const char* lm_version(void) { return "lm_engine 0.3 (gfx950, abi 3)"; }
+const char* lm_version(void) { return "lm_engine 0.4 (gfx950, abi 4)"; }
 int lm_abi_version(void) { return LM_ABI_VERSION; }
 
 int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks, int split_env, uint32_t seed) {
@@ -1796,8 +1795,6 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     const lm_params& p = params[t];
     if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
       return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
-    if (p.sat_probe < 0 || p.sat_probe > p.pgs_iters || (p.sat_probe & 1) || (p.sat_probe == 0 && p.pgs_iters > 0))
-      return fail(LM_EINVAL, "lm_create: sat_probe must be an even sweep count in [2, pgs_iters] (the sweeps alternate direction in pairs)");
     if (p.drive_mode < 0 || p.drive_mode > 2 || (p.drive_mode != 0 && p.variant != 0) || (p.drive_mode == LM_DRIVE_POSITION && !(p.kd > 0)))
       return fail(LM_EINVAL, "lm_create: drive_mode must be 0 (velocity), 1 (position: kd > 0) or 2 (effort), and 0 for the PD-actuator variants");
     if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || p.variant < 0 || p.variant > 2 ||

@@ -161,10 +161,6 @@ class EngineParams:
     # ---- RobotOmni.take_action control mode (robot/base/robot.py:444-461), variant 0 only: 0 velocity (every task of the path), 1 position
     # (target a * act_scale rad with act_scale = pi, PD gains pd_kp / kd), 2 effort (torque a * act_scale N m with act_scale = torque limit)
     drive_mode: int = 0
-    # PD-actuator families (variants 1 / 2): sweeps of the first drive pass after which saturation is tested.  Nearly every sub-step
-    # saturates a joint there (a real 1.5 N m clamp), so the first pass only has to find out WHICH joints: -1 = min(4, pgs_iters).  The velocity-drive
-    # tasks (variant 0) test after the full solve and ignore the value
-    sat_probe: int = -1
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 
@@ -173,8 +169,6 @@ class EngineParams:
             self.tau_max = self.max_effort / self.dt if (self.drive_limits_are_impulses and self.dt > 0) else self.max_effort
         if self.pgs_iters < 0:
             self.pgs_iters = PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE
-        if self.sat_probe < 0:
-            self.sat_probe = min(4, self.pgs_iters) if self.variant != 0 else self.pgs_iters
 
     @property
     def ctrl_dt(self) -> float:

@@ -350,6 +350,14 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
   /* effort mode (robot.py:455-459): the action is the joint torque itself, gains off - the constant-torque branch of the drive from the start */
   const int effort = (p->variant==0 && p->drive_mode==2);
   int sat[12]; real tsat[12]; for (int j=0;j<12;j++){sat[j]=effort;tsat[j]=effort?target[j]:0;}
+  /* PD-actuator families (variants 1 / 2): the reference evaluates  clamp(kp (q* - q) - kd qd, +-max_effort)  on the state BEFORE the
+     sub-step and holds it (quadruped_pose_control_custom_controller.py:289-293), so which joints sit on the limit is known up front:
+     those get the constant limit torque from the first pass on, the others the implicit form of the same PD law (end-of-step velocity: the
+     stable choice at kd dt / I of order 1).  The test after the solve then only catches the few unsaturated joints whose implicit torque left the
+     limit (0.2 % of the joint-sub-steps under random actions) and re-solves with those on the limit too: the applied torque never exceeds max_effort.
+     (PhysX's own drives - variant 0 with a finite tau_max - limit the force of an implicit drive, which only the solve can tell.) */
+  const int pd = (p->variant!=0);
+  if (pd) for (int j=0;j<12;j++) { real tau=kd*(target[j]-u[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;} }
   real un[NU];
   for (int pass=0; pass<2; pass++) {
     real L[NU][NU]; memcpy(L, D->M, sizeof(L)); real rhs[NU];
@@ -363,12 +371,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     for (int r=0;r<12;r++) { for (int c=0;c<12;c++){ real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*MiJ[c][a]; W[r][c]=s; }
       real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*uf[a]; vf[r]=s; lam[r]=0; }
     if (g_cap_W) { for (int r=0;r<12;r++) { for (int c=0;c<12;c++) g_cap_W[12*r+c]=W[r][c]; g_cap_vf[r]=vf[r]; } for (int i=0;i<4;i++) g_cap_bn[i]=bn[i]; }
-    /* the first pass tests for drive saturation after sat_probe sweeps: a cheap look at which joints the contact loads overpower.  If none does,
-       the same solve simply continues to pgs_iters (identical to an uninterrupted solve); otherwise the second pass re-solves with the full count */
-    int probe = (pass==0 && p->variant!=0 && p->sat_probe>0 && p->sat_probe<p->pgs_iters) ? p->sat_probe : p->pgs_iters;      /* PD-actuator families only */
-    int it0 = 0;
-  sweep_more:
-    for (int it=it0; it<probe; it++) for (int ii=0;ii<4;ii++) {
+    for (int it=0; it<p->pgs_iters; it++) for (int ii=0;ii<4;ii++) {
       const int i=(it&1)?3-ii:ii;      /* sweeps alternate direction: no limb is systematically relaxed first */
       int r=3*i; real v=vf[r]+bn[i]; for (int c=0;c<12;c++) v+=W[r][c]*lam[c];
       real ln=lam[r]-v/W[r][r]; if (ln<0) ln=0; lam[r]=ln;
@@ -384,9 +387,9 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
     if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];
-    if (pass==0) { if (it0>0) break;      /* the continued solve of an env that passed the (one) saturation test: final */
-      int any=0; if (!effort) for (int j=0;j<12;j++) { real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
-      if (!any) { if (probe<p->pgs_iters) { it0=probe; probe=p->pgs_iters; goto sweep_more; } break; } }
+    if (pass==0) { if (effort) break;
+      int any=0; for (int j=0;j<12;j++) { if (sat[j]) continue; real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
+      if (!any) break; }
   }
   if (tau_out) for (int j=0;j<12;j++) tau_out[j] = sat[j] ? tsat[j] : kd*(target[j]-un[6+j]);   /* drive torque applied over this sub-step */
   /* integrate; driven joints are speed-limited like PhysX's maxJointVelocity (Design/Scripts/config_module_joints.py:11,61-69) */

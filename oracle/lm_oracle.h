@@ -138,8 +138,7 @@ typedef struct {
   lmo_dr_channel dr[LMO_DR_CHANNELS];
   int32_t drive_mode;        /* variant 0: RobotOmni.take_action's control mode (robot/base/robot.py:444-461): 0 velocity target a*act_scale,
                                 1 position target a*act_scale with tau = pd_kp (q* - q) - kd qd per sub-step, 2 effort tau = a*act_scale */
-  int32_t sat_probe;         /* variants 1 / 2: sweeps of the first drive pass after which saturation is tested (engine_config.py: sat_probe); the pass continues to
-                                pgs_iters when no joint of the env saturates, otherwise the saturated set is re-solved with the full count */
+  int32_t pad1;
 } lmo_params;
 
 /* per-env physical state, env-major */

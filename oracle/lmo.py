@@ -60,7 +60,7 @@ class LmoParams(C.Structure):
         ("se_lo", C.c_double * 12), ("se_hi", C.c_double * 12), ("init_se", C.c_double * 12), ("torque_div", C.c_double),
         ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
         ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmoDrChannel * 9),
-        ("drive_mode", C.c_int32), ("sat_probe", C.c_int32),
+        ("drive_mode", C.c_int32), ("pad1", C.c_int32),
     ]
 
 
@@ -108,6 +108,8 @@ def make_params(ep) -> LmoParams:
     for name, ctype in LmoParams._fields_:
         if name == "pyramid":
             p.pyramid = int(getattr(ep, "pyramid", 0)); continue
+        if name == "pad1":
+            continue
         if name == "dr":
             for i, ch in enumerate(ep.dr):
                 p.dr[i].enabled, p.dr[i].operation, p.dr[i].distribution, p.dr[i].interval = int(ch.enabled), int(ch.operation), int(ch.distribution), int(ch.interval)
@@ -164,6 +166,13 @@ class Oracle:
         assert phys.dtype == self.dtype and phys.flags.c_contiguous
         targets = self._arr(targets, (phys.shape[0], 12))
         self.lib.lmo_substep(C.byref(self.model), C.byref(self.params), C.c_int(phys.shape[0]), self._p(phys), self._p(targets))
+
+    def substep_tau(self, phys, targets):
+        """One sub-step that also returns the drive torque applied over it (what the PD-actuator tasks log)."""
+        assert phys.dtype == self.dtype and phys.flags.c_contiguous
+        targets = self._arr(targets, (phys.shape[0], 12)); tau = np.zeros((phys.shape[0], 12), self.dtype)
+        self.lib.lmo_substep_tau(C.byref(self.model), C.byref(self.params), C.c_int(phys.shape[0]), self._p(phys), self._p(targets), self._p(tau))
+        return tau
 
     def dyn_terms(self, phys_row):
         phys_row = self._arr(phys_row, (PHYS,))

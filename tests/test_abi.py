@@ -77,8 +77,6 @@ def test_argument_validation_without_gpu(so):
     assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1
     bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(variant=1)))                    # custom controller needs the 88-wide observation
     assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1 and b"variant" in so.lm_last_error()
-    bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(variant=1, num_obs=88, sat_probe=3)))          # the sweeps alternate direction in pairs
-    assert so.lm_create(C.byref(h), 64, tab.ctypes.data_as(C.c_void_p), bad, 1, 0, 0) == -1 and b"sat_probe" in so.lm_last_error()
     from locomanipulationrl_amd.engine_config import DRChannel
     dr = [DRChannel() for _ in range(8)]; dr[1] = DRChannel(enabled=1, operation=0, distribution=0, interval=0)      # on_interval noise without an interval
     bad = (lmlib.LmParams * 1)(lmlib.make_params(loco_params(dr_enabled=1, dr=dr)))
