@@ -105,6 +105,11 @@ typedef struct lm_params {
                                 LM_DRIVE_VELOCITY  target = a * act_scale [rad/s]           implicit damper kd (the mode every task of the path uses)
                                 LM_DRIVE_POSITION  target = a * act_scale [rad] (act_scale = pi); tau = pd_kp (q* - q) - kd qd, re-evaluated per sub-step
                                 LM_DRIVE_EFFORT    tau = a * act_scale [N m] (act_scale = torque limit), gains off */
+  int32_t pd_second_pass;    /* variants 1 / 2.  0 (default): which joints sit on the +-tau_max limit is decided from the PD torque on the state BEFORE
+                                the sub-step, as the reference's explicit clamp decides it (quadruped_pose_control_custom_controller.py:289-293); the others
+                                get the implicit form of the law in ONE pass, and the 0.02 % of joint-sub-steps whose implicit torque then leaves the
+                                limit keep it.  1: those joints are put on the limit too and the sub-step is solved a second time (the applied
+                                torque never exceeds tau_max; a step then takes as long as its slowest wavefront: +6 us at 4096 envs).  DESIGN.md 3.3 */
   /* derived by lm_create (callers leave zero) */
   float plate_si[10];      /* plate spatial inertia about its origin */
   float plate_phi[36];     /* its inverse */

@@ -492,6 +492,14 @@ LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
 }
 
 
+#ifdef LM_COUNT_PASS2      // diagnostic builds only (tools/pass2_count.py): wavefront-sub-steps run / of those with a second drive pass
+__device__ unsigned int lm_dbg_pass2[2];
+extern "C" void lm_dbg_pass2_read(unsigned int* out, int clear) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(lm_dbg_pass2), sizeof(lm_dbg_pass2));
+  if (clear) { unsigned int z[2] = {0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(lm_dbg_pass2), z, sizeof(z)); }
+}
+#endif
+
 // One physics sub-step of one env (4 lanes).  MODE 0: F is the robot base.  MODE 1: F is the plate, the
 // robot base is fixed at (Rb, pb).
 template <int MODE, int VAR, int DR>
@@ -587,10 +595,11 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   bool sat[3] = {effort, effort, effort}; float tsat[3] = {effort ? tgt[0] : 0.f, effort ? tgt[1] : 0.f, effort ? tgt[2] : 0.f};
   // PD-actuator families: the reference evaluates  clamp(kp (q* - q) - kd qd, +-max_effort)  on the state BEFORE the sub-step and holds it
   // (quadruped_pose_control_custom_controller.py:289-293), so which joints sit on the limit is known up front: those get the constant limit
-  // torque from the first pass on, the others the implicit form of the same PD law.  The test after the solve then only catches the few
-  // unsaturated joints whose implicit (end-of-step) torque left the limit - 0.2 % of the joint-sub-steps under random actions, so the second
-  // pass runs in about a tenth of the wavefront-sub-steps instead of all of them - and the applied torque never exceeds max_effort.
-  // (Variant 0 with a finite tau_max limits the force of an implicit drive, which only the solve can tell.)
+  // torque, the others the implicit form of the same PD law, in ONE pass.  The implicit (end-of-step) torque of an unsaturated joint leaves the
+  // limit in 0.02 % of the joint-sub-steps under random actions; lm_params.pd_second_pass = 1 puts those on the limit too and solves again.  That
+  // happens in 1-3 % of the wavefront-sub-steps (tools/pass2_count.py), but a step lasts as long as its slowest wavefront and one of the 256
+  // nearly always has one: +6 us per step, which is why it is off by default.
+  // (Variant 0 with a finite tau_max limits the force of an implicit drive, which only the solve can tell: two passes.)
   if (VAR) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -724,7 +733,7 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     }
     LM_STAMP(4);
     if (pass == 0) {
-      if (effort) break;
+      if (effort || (VAR != 0 && !P->pd_second_pass)) break;
       int any = 0;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -738,6 +747,9 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
         }
       }
       any = quad_sum_i(any);
+#ifdef LM_COUNT_PASS2
+      { const bool wa = __any(any); if ((threadIdx.x & 63) == 0) { atomicAdd(&lm_dbg_pass2[0], 1u); if (wa) atomicAdd(&lm_dbg_pass2[1], 1u); } }
+#endif
       if (!__any(any)) break;                  // wave-uniform: nobody saturated
       // envs without saturation redo the identical unsaturated solve in pass 1 (same result)
     }
@@ -1795,6 +1807,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
     const lm_params& p = params[t];
     if (!(p.dt > 0) || p.substeps <= 0 || p.pgs_iters < 0 || (p.mode != LM_MODE_LOCO && p.mode != LM_MODE_MANI))
       return fail(LM_EINVAL, "lm_create: invalid dt / substeps / pgs_iters / mode");
+    if (p.pd_second_pass < 0 || p.pd_second_pass > 1) return fail(LM_EINVAL, "lm_create: pd_second_pass must be 0 or 1");
     if (p.drive_mode < 0 || p.drive_mode > 2 || (p.drive_mode != 0 && p.variant != 0) || (p.drive_mode == LM_DRIVE_POSITION && !(p.kd > 0)))
       return fail(LM_EINVAL, "lm_create: drive_mode must be 0 (velocity), 1 (position: kd > 0) or 2 (effort), and 0 for the PD-actuator variants");
     if ((p.num_obs != 64 && p.num_obs != LM_MAX_OBS) || p.num_obs != params[0].num_obs || p.variant < 0 || p.variant > 2 ||

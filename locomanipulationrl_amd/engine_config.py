@@ -161,6 +161,10 @@ class EngineParams:
     # ---- RobotOmni.take_action control mode (robot/base/robot.py:444-461), variant 0 only: 0 velocity (every task of the path), 1 position
     # (target a * act_scale rad with act_scale = pi, PD gains pd_kp / kd), 2 effort (torque a * act_scale N m with act_scale = torque limit)
     drive_mode: int = 0
+    # PD-actuator families (variants 1 / 2).  0: the joints on the +-tau_max limit are those whose PD torque on the pre-step state is outside it (the
+    # reference's explicit clamp, ...custom_controller.py:289-293), one pass.  1: unsaturated joints whose implicit end-of-step torque left the limit
+    # (0.02 % of the joint-sub-steps) are put on it too and the sub-step is solved again (+6 us per step at 4096 envs)
+    pd_second_pass: int = 0
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 

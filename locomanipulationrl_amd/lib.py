@@ -64,7 +64,7 @@ class LmParams(C.Structure):
         ("se_lo", C.c_float * 12), ("se_hi", C.c_float * 12), ("init_se", C.c_float * 12),
         ("torque_div", C.c_float), ("power_scale", C.c_float), ("target_err_scale", C.c_float), ("rot_dec_scale", C.c_float),
         ("rot_dec_thresh", C.c_float), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
-        ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmDrChannel * 9), ("drive_mode", C.c_int32),
+        ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmDrChannel * 9), ("drive_mode", C.c_int32), ("pd_second_pass", C.c_int32),
         ("plate_si", C.c_float * 10), ("plate_phi", C.c_float * 36), ("ctrl_dt_inv", C.c_float), ("acc_dt_inv", C.c_float),
     ]
 

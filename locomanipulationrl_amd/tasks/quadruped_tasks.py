@@ -103,7 +103,7 @@ class _QuadrupedTask(RLTask):
             dt=float(sim["dt"]), substeps=int(self.control_frequency_inv), pgs_iters=int(sweeps), gravity=float(-g[2]),
             kd=float(rd.joint_kds[0]), max_effort=float(rd.torque_limits[0]), drive_limits_are_impulses=bool(eng.get("drive_limits_are_impulses", True)), act_scale=float(rd.velocity_limits[0]), mu=mu, drive_mode=0,
             tip_radius=float(eng.get("tip_radius", 0.005)), baumgarte=float(eng.get("baumgarte", 0.2)),
-            max_depen_vel=float(eng.get("max_depenetration_velocity", 1.0)),
+            max_depen_vel=float(eng.get("max_depenetration_velocity", 1.0)), pd_second_pass=int(bool(eng.get("pd_second_pass", False))),
             max_joint_vel=float(eng.get("max_joint_velocity_deg", 450.0)) * 3.141592653589793 / 180.0,
             init_q=list(rd.init_joint_pos[:12]),
             goal_lo=[self.min_roll, self.min_pitch, self.min_yaw], goal_hi=[self.max_roll, self.max_pitch, self.max_yaw],

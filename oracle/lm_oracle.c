@@ -352,10 +352,10 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
   int sat[12]; real tsat[12]; for (int j=0;j<12;j++){sat[j]=effort;tsat[j]=effort?target[j]:0;}
   /* PD-actuator families (variants 1 / 2): the reference evaluates  clamp(kp (q* - q) - kd qd, +-max_effort)  on the state BEFORE the
      sub-step and holds it (quadruped_pose_control_custom_controller.py:289-293), so which joints sit on the limit is known up front:
-     those get the constant limit torque from the first pass on, the others the implicit form of the same PD law (end-of-step velocity: the
-     stable choice at kd dt / I of order 1).  The test after the solve then only catches the few unsaturated joints whose implicit torque left the
-     limit (0.2 % of the joint-sub-steps under random actions) and re-solves with those on the limit too: the applied torque never exceeds max_effort.
-     (PhysX's own drives - variant 0 with a finite tau_max - limit the force of an implicit drive, which only the solve can tell.) */
+     those get the constant limit torque, the others the implicit form of the same PD law (end-of-step velocity: the stable choice at
+     kd dt / I of order 1), in one pass.  The implicit torque of an unsaturated joint leaves the limit in 0.02 % of the joint-sub-steps under
+     random actions; pd_second_pass = 1 puts those on the limit too and solves again (the applied torque then never exceeds max_effort).
+     (PhysX's own drives - variant 0 with a finite tau_max - limit the force of an implicit drive, which only the solve can tell: two passes.) */
   const int pd = (p->variant!=0);
   if (pd) for (int j=0;j<12;j++) { real tau=kd*(target[j]-u[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;} }
   real un[NU];
@@ -387,7 +387,7 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     }
     for (int a=0;a<NU;a++) { real s=uf[a]; for (int r=0;r<12;r++) s+=MiJ[r][a]*lam[r]; un[a]=s; }
     if (g_cap_lam) for (int r=0;r<12;r++) g_cap_lam[r]=lam[r];
-    if (pass==0) { if (effort) break;
+    if (pass==0) { if (effort || (pd && !p->pd_second_pass)) break;
       int any=0; for (int j=0;j<12;j++) { if (sat[j]) continue; real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
       if (!any) break; }
   }

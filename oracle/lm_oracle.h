@@ -138,7 +138,7 @@ typedef struct {
   lmo_dr_channel dr[LMO_DR_CHANNELS];
   int32_t drive_mode;        /* variant 0: RobotOmni.take_action's control mode (robot/base/robot.py:444-461): 0 velocity target a*act_scale,
                                 1 position target a*act_scale with tau = pd_kp (q* - q) - kd qd per sub-step, 2 effort tau = a*act_scale */
-  int32_t pad1;
+  int32_t pd_second_pass;    /* variants 1 / 2: 1 = unsaturated joints whose implicit torque left the limit are put on it and the sub-step is solved again (engine_config.py) */
 } lmo_params;
 
 /* per-env physical state, env-major */

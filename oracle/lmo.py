@@ -60,7 +60,7 @@ class LmoParams(C.Structure):
         ("se_lo", C.c_double * 12), ("se_hi", C.c_double * 12), ("init_se", C.c_double * 12), ("torque_div", C.c_double),
         ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
         ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmoDrChannel * 9),
-        ("drive_mode", C.c_int32), ("pad1", C.c_int32),
+        ("drive_mode", C.c_int32), ("pd_second_pass", C.c_int32),
     ]
 
 
@@ -108,8 +108,6 @@ def make_params(ep) -> LmoParams:
     for name, ctype in LmoParams._fields_:
         if name == "pyramid":
             p.pyramid = int(getattr(ep, "pyramid", 0)); continue
-        if name == "pad1":
-            continue
         if name == "dr":
             for i, ch in enumerate(ep.dr):
                 p.dr[i].enabled, p.dr[i].operation, p.dr[i].distribution, p.dr[i].interval = int(ch.enabled), int(ch.operation), int(ch.distribution), int(ch.interval)

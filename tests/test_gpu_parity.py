@@ -219,16 +219,17 @@ def test_full_step_parity_from_identical_states(robot_model, engine_cls, oracle_
     eng.close()
 
 
+@pytest.mark.parametrize("second_pass", [0, 1])
 @pytest.mark.parametrize("case", ["nobody saturates", "everybody saturates", "mixed inside every wavefront"])
-def test_pd_actuator_clamp_decided_before_the_substep(robot_model, engine_cls, oracle_cls, case):
+def test_pd_actuator_clamp_decided_before_the_substep(robot_model, engine_cls, oracle_cls, case, second_pass):
     """PD-actuator families: which joints sit on the +-1.5 N m limit is decided from the state BEFORE the sub-step, as the reference's explicit
     clamp(kp (q* - q) - kd qd) is (quadruped_pose_control_custom_controller.py:289-293): those joints get the constant limit
-    torque, the others the implicit form of the PD law, in ONE pass.  Compared with the oracle for wavefronts in which no joint, nearly every
-    joint, and every second env's joints saturate; the logged torque (the mean of the sub-step torques, observation columns 64:76 of the
-    custom-controller task) never leaves the limit."""
+    torque, the others the implicit form of the PD law, in ONE pass; with `pd_second_pass` the unsaturated joints whose implicit torque left the
+    limit are put on it too and the sub-step is solved again.  Both settings are compared with the oracle for wavefronts in which no joint,
+    nearly every joint, and every second env's joints saturate."""
     N = 128
     big = 1.0e3 if case.startswith("nobody") else 1.5
-    ep = loco_cc_params(tau_max=big)
+    ep = loco_cc_params(tau_max=big, pd_second_pass=second_pass)
     o = oracle_cls(robot_model, ep); eng = engine_cls(robot_model, [ep], N, seed=3)
     rng = np.random.default_rng(9); phys, task, cnt = o.new_state(N)
     for t in range(6):

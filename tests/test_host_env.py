@@ -310,6 +310,6 @@ def test_contact_and_drive_parameters_reach_the_engine_block():
     (clamp,) = blocks("QuadrupedPoseControl", drive_limits_are_impulses=False, friction_scale=1.0, pgs_iters=12)
     assert clamp.tau_max == 1.5 and abs(clamp.mu - 1.0) < 1e-12 and clamp.pgs_iters == 12
     (cc,) = blocks("QuadrupedPoseControlCustomController")
-    assert cc.variant == 1 and cc.tau_max == 1.5 and cc.pgs_iters == 8 and abs(cc.dt - 0.005) < 1e-12
-    lo2, ma2 = blocks("JointLocomanipulationPositionControl", pgs_iters={"ground": 10, "plate": 6})
-    assert (lo2.pgs_iters, ma2.pgs_iters) == (10, 6)
+    assert cc.variant == 1 and cc.tau_max == 1.5 and cc.pd_second_pass == 0 and cc.pgs_iters == 8 and abs(cc.dt - 0.005) < 1e-12
+    lo2, ma2 = blocks("JointLocomanipulationPositionControl", pgs_iters={"ground": 10, "plate": 6}, pd_second_pass=True)
+    assert (lo2.pgs_iters, ma2.pgs_iters, lo2.pd_second_pass, ma2.pd_second_pass) == (10, 6, 1, 1)

@@ -134,22 +134,29 @@ def test_saturated_drive_respects_torque_limit(robot_model):
 def test_pd_actuator_clamp_follows_the_reference_rule(robot_model):
     """PD-actuator families: the reference clamps the PD torque evaluated on the state BEFORE the sub-step
     (quadruped_pose_control_custom_controller.py:289-293).  Every joint whose explicit torque kp (q* - q) - kd qd leaves +-1.5 N m gets exactly the
-    limit torque; the others get the implicit form kd (v* - qd_end), and the few of those whose implicit torque would leave the limit are put on
-    it by the second pass: the applied torque stays inside the limit (a third-order leftover after the second pass is tolerated at 1e-3 of the
-    joint-sub-steps)."""
+    limit torque; the others get the implicit form kd (v* - qd_end) in the same single pass.  The implicit torque of such a joint can leave the
+    limit - in fewer than 1e-3 of the joint-sub-steps of this (rougher than the task's) random walk of targets, by at most kd x the velocity change of
+    the sub-step - and `pd_second_pass` puts those
+    joints on the limit too and solves again: then the applied torque never exceeds it (a third-order leftover is tolerated at 1e-4)."""
     from locomanipulationrl_amd.engine_config import loco_cc_params
-    ep = loco_cc_params(); o = Oracle(robot_model, ep); N = 64
-    phys, task, cnt = o.new_state(N); rng = np.random.default_rng(0)
-    o.step(phys, task, cnt, np.zeros((N, 12)), seed=0)
-    qstar = phys[:, 13:25].copy(); n = n_sat = n_over = 0
-    for t in range(30):
-        qstar = np.clip(qstar + 0.1 * rng.uniform(-1, 1, (N, 12)), phys[:, 13:25] - 1.0, phys[:, 13:25] + 1.0)
-        for s in range(ep.substeps):
-            tg = ep.pd_kp / ep.kd * (qstar - phys[:, 13:25]); tau_e = ep.kd * (tg - phys[:, 25:37])
-            tau = o.substep_tau(phys, tg); S = np.abs(tau_e) > ep.tau_max
-            assert np.allclose(tau[S], np.sign(tau_e[S]) * ep.tau_max)
-            n += S.size; n_sat += int(S.sum()); n_over += int((np.abs(tau) > ep.tau_max * (1 + 1e-9)).sum())
-    assert n_sat > 0.01 * n and n_over <= 1e-3 * n, (n_sat / n, n_over / n)
+    N = 64
+    for second in (0, 1):
+        ep = loco_cc_params(pd_second_pass=second); o = Oracle(robot_model, ep)
+        phys, task, cnt = o.new_state(N); rng = np.random.default_rng(0)
+        o.step(phys, task, cnt, np.zeros((N, 12)), seed=0)
+        qstar = phys[:, 13:25].copy(); n = n_sat = n_over = 0; worst = 0.0
+        for t in range(30):
+            qstar = np.clip(qstar + 0.1 * rng.uniform(-1, 1, (N, 12)), phys[:, 13:25] - 1.0, phys[:, 13:25] + 1.0)
+            for s in range(ep.substeps):
+                tg = ep.pd_kp / ep.kd * (qstar - phys[:, 13:25]); tau_e = ep.kd * (tg - phys[:, 25:37])
+                tau = o.substep_tau(phys, tg); S = np.abs(tau_e) > ep.tau_max
+                assert np.allclose(tau[S], np.sign(tau_e[S]) * ep.tau_max)
+                n += S.size; n_sat += int(S.sum()); n_over += int((np.abs(tau) > ep.tau_max * (1 + 1e-9)).sum()); worst = max(worst, float(np.abs(tau).max()))
+        assert n_sat > 0.01 * n, n_sat / n
+        if second:
+            assert n_over <= 1e-4 * n, n_over / n
+        else:
+            assert 0 < n_over <= 1e-3 * n and worst < ep.tau_max + ep.kd * 2 * ep.max_joint_vel, (n_over / n, worst)      # the excess is the implicit damping of one sub-step's velocity change
 
 
 def test_effort_and_position_control_modes(robot_model):
