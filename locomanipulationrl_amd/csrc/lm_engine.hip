@@ -1330,43 +1330,58 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   LM_STAMP(10);     // the reduction's round trips
 }
 
-__global__ void __launch_bounds__(64) k_step(StepArgs A) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
-  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
-  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
-  __shared__ float4 sStash[STASH_SLOTS * 64];
-  const int env0 = lm_block() * ENVS_PER_WAVE;
-  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
+// The step kernels.  One launch per step(); a wavefront picks its specialisation (task mode x actuator family) from the kernel arguments.  The
+// velocity-drive tasks (k_step: the headline) and the PD-actuator families (k_step_pd) are separate kernels, so that the register allocation
+// and code layout of the one do not move when the other is edited; both blocks of a co-training engine are of one actuator family (lm_create).
 #ifdef LM_STAMPS
-  if (threadIdx.x < 64) lm_stamp_lds[threadIdx.x] = 0;
-  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
-  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_stamp_lds[16 * (threadIdx.x >> 6) + 15] = t0_; }
-  LM_STAMP(11); LM_STAMP(12);      // two stamps back to back: bucket 12 = the cost of a stamp
+#define LM_STEP_PROLOGUE \
+  if (threadIdx.x < 64) lm_stamp_lds[threadIdx.x] = 0; \
+  __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); \
+  { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); if ((threadIdx.x & 63) == 0) lm_stamp_lds[16 * (threadIdx.x >> 6) + 15] = t0_; } \
+  LM_STAMP(11); LM_STAMP(12);      /* two stamps back to back: bucket 12 = the cost of a stamp */ \
   const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
-#endif
-  const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
-  if (kind == 0) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else if (kind == 1) step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash);
-  else if (kind == 2) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else if (kind == 3) step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash);
-  else if (kind == 4) step_body<0, 2, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(A, P, sTab, sObs, sSt, sStash);
-#ifdef LM_STAMPS
-  { const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime(), mt1_ = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) { lm_stamp_lds[13] = mt1_ - mt0_; lm_stamp_lds[14] = rt1_ - rt0_; } }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
+#define LM_STEP_EPILOGUE \
+  { const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime(), mt1_ = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0) { lm_stamp_lds[13] = mt1_ - mt0_; lm_stamp_lds[14] = rt1_ - rt0_; } } \
+  __builtin_amdgcn_s_waitcnt(0xc07f); \
   if (threadIdx.x < 64 && blockIdx.x < 1024) lm_stamp_out[blockIdx.x * 64 + threadIdx.x] = lm_stamp_lds[threadIdx.x];
+#else
+#define LM_STEP_PROLOGUE
+#define LM_STEP_EPILOGUE
 #endif
+#define LM_STEP_SMEM(NOBS) \
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2]; \
+  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * (NOBS)]; \
+  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93]; \
+  __shared__ float4 sStash[STASH_SLOTS * 64]; \
+  const int env0 = lm_block() * ENVS_PER_WAVE; \
+  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0); \
+  const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
+
+__global__ void __launch_bounds__(64) k_step(StepArgs A) {                 // velocity-drive tasks (kinds 0, 1)
+  LM_STEP_SMEM(64)
+  LM_STEP_PROLOGUE
+  if (kind == 0) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash);
+  LM_STEP_EPILOGUE
 }
 
-// the same step with domain randomisation (a separate kernel so that the un-randomised k_step above is untouched)
+__global__ void __launch_bounds__(64) k_step_pd(StepArgs A) {              // PD-actuator families (kinds 2 ... 5)
+  LM_STEP_SMEM(LM_MAX_OBS)
+  LM_STEP_PROLOGUE
+  if (kind == 2) step_body<0, 1, 0>(A, P, sTab, sObs, sSt, sStash); else if (kind == 3) step_body<1, 1, 0>(A, P, sTab, sObs, sSt, sStash);
+  else if (kind == 4) step_body<0, 2, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 0>(A, P, sTab, sObs, sSt, sStash);
+  LM_STEP_EPILOGUE
+}
+
+// the same steps with domain randomisation (separate kernels so that the un-randomised ones above are untouched)
 __global__ void __launch_bounds__(64) k_step_dr(StepArgs A) {
-  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2];
-  __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * LM_MAX_OBS];
-  __shared__ __attribute__((aligned(16))) float sSt[ENVS_PER_WAVE * 93];
-  __shared__ float4 sStash[STASH_SLOTS * 64];
-  const int env0 = lm_block() * ENVS_PER_WAVE;
-  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0);
-  const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
-  if (kind == 0) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else if (kind == 1) step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash);
-  else if (kind == 2) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else if (kind == 3) step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash);
+  LM_STEP_SMEM(64)
+  if (kind == 0) step_body<0, 0, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 1>(A, P, sTab, sObs, sSt, sStash);
+}
+
+__global__ void __launch_bounds__(64) k_step_dr_pd(StepArgs A) {
+  LM_STEP_SMEM(LM_MAX_OBS)
+  if (kind == 2) step_body<0, 1, 1>(A, P, sTab, sObs, sSt, sStash); else if (kind == 3) step_body<1, 1, 1>(A, P, sTab, sObs, sSt, sStash);
   else if (kind == 4) step_body<0, 2, 1>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 2, 1>(A, P, sTab, sObs, sSt, sStash);
 }
 
@@ -1814,6 +1829,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
         (p.variant == 1) != (p.num_obs == LM_MAX_OBS) || (p.variant >= 1 && !(p.kd > 0 && p.torque_div > 0 && p.acc_substeps >= 1 && p.acc_substeps <= p.substeps)))
       return fail(LM_EINVAL, "lm_create: invalid variant / num_obs (64 for velocity-drive and position-control tasks, 88 for custom-controller tasks, equal across tasks) or acc_substeps");
     if ((p.dr_enabled != 0) != (params[0].dr_enabled != 0)) return fail(LM_EINVAL, "lm_create: dr_enabled must be equal across tasks");
+    if ((p.variant != 0) != (params[0].variant != 0)) return fail(LM_EINVAL, "lm_create: both parameter blocks must be of one actuator family (velocity drive: variant 0; PD actuator: variants 1 / 2)");
     if (p.dr_enabled) for (int c = 0; c < LM_DR_CHANNELS; c++) {
       const lm_dr_channel& ch = p.dr[c];
       if (!ch.enabled) continue;
@@ -1909,8 +1925,9 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
   CHECK_DEVICE(h, "lm_step");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
-  if (h->dr_enabled) hipLaunchKernelGGL(k_step_dr, dim3(h->nblocks), dim3(64), 0, s, A);
-  else hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
+  const bool pd = A.kind[0] >= 2;                                  // both blocks are of one actuator family (lm_create)
+  void (*kern)(StepArgs) = h->dr_enabled ? (pd ? k_step_dr_pd : k_step_dr) : (pd ? k_step_pd : k_step);
+  hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(64), 0, s, A);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -1923,7 +1940,8 @@ int lm_post_physics(lm_engine* h, const float* actions, float* out_obs, float* o
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, nullptr, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   A.skip_reset = 1; A.nsub = 0;
-  hipLaunchKernelGGL(k_step, dim3(h->nblocks), dim3(64), 0, s, A);
+  void (*kern)(StepArgs) = A.kind[0] >= 2 ? k_step_pd : k_step;
+  hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(64), 0, s, A);
   HIPCHK(hipGetLastError());
   return LM_OK;
 }

@@ -8,7 +8,7 @@ def collect(d):
     acc = collections.defaultdict(list); waves = 256
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("k_step"):
+            if r["Kernel_Name"].split("(")[0].strip() == "k_step":      # the velocity-drive step kernel (k_step_pd, k_step_dr are others)
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"])); waves = int(r["Grid_Size"]) // 64
     return {k: sum(v) / len(v) / waves for k, v in acc.items()}, waves
 
