@@ -189,6 +189,7 @@ def main():
         one_step(t)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # HIP events on the launch stream, around the timed region
+    ev0.record(); ev1.record(); torch.cuda.synchronize(dev)      # torch creates the HIP events at their first record: not inside the timed region
     t0 = time.perf_counter()
     ev0.record()
     for t in range(args.steps):
