@@ -31,7 +31,7 @@ trajectories (tests/golden/npy_traj.npz; tests/npy_replay
       on PhysX's row, 97 of PhysX's 119 window rows are shared (pyramid: 59).  The coefficient: all seven episodes enter for mu in
       [0.75, 0.85] x nominal, five of seven at the nominal 1.0 (tables in DESIGN.md 2.1) - a fitted effective coefficient, parity unpinned (PhysX's
       friction rows are part of an unconverged iterative solve; a link material at PhysX's default 0.5 averaged with the ground's 1.0 would
-      give 0.75, the robot's USD is not in the reference).  8 sweeps = round 2's count, well inside the flat range.
+      give 0.75, the robot's USD is not in the reference).  Sweep counts: see PGS_ITERS_* below.
 """
 from __future__ import annotations
 
@@ -39,7 +39,12 @@ from dataclasses import dataclass, field, replace
 from typing import List
 
 
-PGS_ITERS_GROUND, PGS_ITERS_PLATE = 8, 8
+# Contact sweeps per solve, chosen on convergence (DESIGN.md 2.1, table `convergence` of tests/npy_replay_evidence.py): the smallest count of 4, 8,
+# 16 ... whose contact velocity change is within 1 % (median) / 20 % (90th percentile) of the 128-sweep solve's on states from random-action
+# rollouts.  The rigid velocity drives couple the four feet through the base (ground: 8 sweeps: 0.6 % / 12 %; 4 sweeps: 6 % / 33 %); the plate
+# (4: 0.0 % / 0.9 %) and the soft PD actuators of the f-1 families (4: 0.1 % / 0.8 %) converge faster.  The replayed PhysX episodes do not tell
+# 2 sweeps from 128 (same section).
+PGS_ITERS_GROUND, PGS_ITERS_PLATE, PGS_ITERS_PD = 8, 4, 4
 FRICTION_SCALE = 0.8             # effective / nominal friction coefficient (see the module docstring)
 MODE_LOCO = 0    # free base on a ground plane
 MODE_MANI = 1    # fixed (inverted) base + free plate
@@ -172,7 +177,7 @@ class EngineParams:
         if self.tau_max < 0:
             self.tau_max = self.max_effort / self.dt if (self.drive_limits_are_impulses and self.dt > 0) else self.max_effort
         if self.pgs_iters < 0:
-            self.pgs_iters = PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE
+            self.pgs_iters = PGS_ITERS_PD if self.variant != 0 else PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE
 
     @property
     def ctrl_dt(self) -> float:

@@ -96,7 +96,7 @@ class _QuadrupedTask(RLTask):
         # `sim.engine.drive_limits_are_impulses: False` selects the 1.5 N m torque clamp.  The PD-actuator tasks clamp their torque in Python
         # (…custom_controller.py:289-307): a real 1.5 N m either way.
         mode = kw.get("mode", MODE_LOCO)
-        sweeps = eng.get("pgs_iters", {})          # contact sweeps per solve: {ground: 8, plate: 8}; a plain integer sets both
+        sweeps = eng.get("pgs_iters", {})          # contact sweeps per solve: {ground: 8, plate: 4}, {ground: 4, plate: 4} for the PD-actuator tasks (engine_config.PGS_ITERS_*); a plain integer sets both
         if isinstance(sweeps, dict):
             sweeps = sweeps.get("ground" if mode == MODE_LOCO else "plate", -1)
         base = dict(

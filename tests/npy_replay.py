@@ -107,3 +107,27 @@ def oracle_stepper(robot_model, ep, precision="f64"):
 def summary_line(name, r):
     return (f"{name:30s} T-1={r['T'] - 1:3d} row0={r['row0_err']:.4f} tracked={r['tracked']:.3f} qerr={r['qerr']:.3f} early={r['early']:.4f} "
             f"done_at={r['done_at']}{'G' if r['goal'] else ''} first<=0.15:{r['first_succ']} (PhysX {r['succ_row']}) min rd={r['rd_rec'].min():.3f} last rd={r['rd_rec'][-1]:.3f} in-window {r['in_window']}/17")
+
+
+def sweep_convergence(robot_model, ep, counts, N=128, steps=24, every=4, seed=0):
+    """Relative error of the contact velocity change of ONE sub-step (base / plate twist + 12 joint rates) against the 128-sweep solve, from
+    identical states sampled along a random-action rollout of `ep` with random drive targets: {count: array over the envs with an active
+    contact}.  The criterion behind engine_config.PGS_ITERS_*: median <= 1 %, 90th percentile <= 20 %, at least 4 sweeps."""
+    from dataclasses import replace
+    from oracle.lmo import Oracle
+    o = Oracle(robot_model, ep); phys, task, cnt = o.new_state(N); rng = np.random.default_rng(seed)
+    o.step(phys, task, cnt, np.zeros((N, 12)), seed=0)
+    solvers = {k: Oracle(robot_model, replace(ep, pgs_iters=k)) for k in set(counts) | {0, 128}}
+    acc = {k: [] for k in counts}
+    for t in range(steps):
+        o.step(phys, task, cnt, rng.uniform(-1, 1, (N, 12)), seed=0)
+        if t % every:
+            continue
+        tg = ep.act_scale * rng.uniform(-1, 1, (N, 12)); res = {}
+        for k, ok in solvers.items():
+            ph = phys.copy(); ok.substep(ph, tg)
+            res[k] = np.concatenate([ph[:, 7:13] if ep.mode == 0 else ph[:, 44:50], ph[:, 25:37]], 1)
+        den = np.linalg.norm(res[128] - res[0], axis=1); m = den > 1e-3
+        for k in counts:
+            acc[k].append(np.linalg.norm(res[k] - res[128], axis=1)[m] / den[m])
+    return {k: np.concatenate(v) for k, v in acc.items()}

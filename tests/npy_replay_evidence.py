@@ -17,6 +17,8 @@ Tables
   row0        one control period after reset under zero action: max |q - recording| per kind for drive limit x depenetration rule; the
               recorded deflection (4.2e-3 rad on the ground, 1.27e-2 rad under the plate) against this engine's
   row0_subiterated   the plate scene's row 0 with the drive limit clamped per solver iteration (K sub-iterations per step): PhysX's 16 reproduces its deflection
+  convergence relative error of one sub-step's contact velocity change against the 128-sweep solve, per surface / actuator family and sweep count
+              (states from random-action rollouts): the criterion behind engine_config.PGS_ITERS_* (median <= 1 %, 90th percentile <= 20 %, at least 4 sweeps)
   files       the per-file outcome of the shipped specification
   link_clearance   how close the (unmodelled) link hulls come to the ground / the plate before a reset fires
 """
@@ -116,6 +118,16 @@ def main():
         row = dict(sub_iterations=K, err=round(float(np.abs(d - ref).max()), 4), joints_within_1e3=int((np.abs(d - ref) < 1e-3).sum()),
                    engine_deflection=[round(float(x), 4) for x in d], physx_deflection=[round(float(x), 4) for x in ref])
         doc["row0_subiterated"].append(row); print(row, flush=True)
+    print("== convergence of the contact solve: relative error of a sub-step's contact velocity change against 128 sweeps")
+    from locomanipulationrl_amd.engine_config import loco_cc_params, loco_params, mani_cc_params, mani_params
+    doc["convergence"] = []
+    for label, ep in (("ground, velocity drive (QuadrupedPoseControl)", loco_params()), ("ground, velocity drive, co-training scene", R.cotrain_params("loco")),
+                      ("plate, velocity drive (QuadrupedManipulatePlate)", mani_params()), ("plate, velocity drive, co-training scene", R.cotrain_params("mani")),
+                      ("ground, PD actuator (custom controller)", loco_cc_params()), ("plate, PD actuator (custom controller)", mani_cc_params())):
+        conv = R.sweep_convergence(rm, ep, [1, 2, 4, 8, 16, 32], N=256, steps=40)
+        for k, e in conv.items():
+            row = dict(case=label, pgs_iters=k, shipped=bool(k == ep.pgs_iters), envs=int(len(e)), median=round(float(np.median(e)), 4), p90=round(float(np.percentile(e, 90)), 4), p99=round(float(np.percentile(e, 99)), 4))
+            doc["convergence"].append(row); print(row, flush=True)
     print("== per file (shipped specification; replays held still for up to 2 rows after the recording to let a late streak complete)")
     doc["files"] = []
     runs = run(rm, rec, until_done=False); held = run(rm, rec, R.GOAL_KNOWN, until_done=True)

@@ -303,13 +303,13 @@ def test_contact_and_drive_parameters_reach_the_engine_block():
         return task_map()[name](name=name, sim_config=SimConfig(cfg), env=None).engine_params()
 
     lo, ma = blocks("JointLocomanipulation")
-    assert lo.mode == 0 and ma.mode == 1 and abs(lo.mu - 0.8) < 1e-12 and abs(ma.mu - 0.8) < 1e-12 and lo.pgs_iters == 8 and ma.pgs_iters == 8
+    assert lo.mode == 0 and ma.mode == 1 and abs(lo.mu - 0.8) < 1e-12 and abs(ma.mu - 0.8) < 1e-12 and lo.pgs_iters == 8 and ma.pgs_iters == 4
     assert abs(lo.tau_max - 1.5 / 0.0083) < 1e-9 and lo.variant == 0
     (single,) = blocks("QuadrupedPoseControl")                       # material 2.0 averaged with the ground plane's 0.0 (rl_task.py:130), times 0.8
     assert abs(single.mu - 0.8) < 1e-12
     (clamp,) = blocks("QuadrupedPoseControl", drive_limits_are_impulses=False, friction_scale=1.0, pgs_iters=12)
     assert clamp.tau_max == 1.5 and abs(clamp.mu - 1.0) < 1e-12 and clamp.pgs_iters == 12
     (cc,) = blocks("QuadrupedPoseControlCustomController")
-    assert cc.variant == 1 and cc.tau_max == 1.5 and cc.pd_second_pass == 0 and cc.pgs_iters == 8 and abs(cc.dt - 0.005) < 1e-12
+    assert cc.variant == 1 and cc.tau_max == 1.5 and cc.pd_second_pass == 0 and cc.pgs_iters == 4 and abs(cc.dt - 0.005) < 1e-12
     lo2, ma2 = blocks("JointLocomanipulationPositionControl", pgs_iters={"ground": 10, "plate": 6}, pd_second_pass=True)
     assert (lo2.pgs_iters, ma2.pgs_iters, lo2.pd_second_pass, ma2.pd_second_pass) == (10, 6, 1, 1)

@@ -159,6 +159,20 @@ def test_pd_actuator_clamp_follows_the_reference_rule(robot_model):
             assert 0 < n_over <= 1e-3 * n and worst < ep.tau_max + ep.kd * 2 * ep.max_joint_vel, (n_over / n, worst)      # the excess is the implicit damping of one sub-step's velocity change
 
 
+def test_shipped_sweep_counts_meet_the_convergence_criterion(robot_model):
+    """engine_config.PGS_ITERS_*: the contact velocity change of a sub-step is within 1 % (median) / 20 % (90th percentile) of the 128-sweep
+    solve's with the shipped counts - 8 on the ground under the rigid velocity drives, 4 on the plate and for the soft PD actuators - and
+    half the ground's count is NOT (the feet couple through the base: 6 % / 33 %), so the ground's count is not padded either.  States from
+    random-action rollouts; the full table is `convergence` in profiles/r03_npy_replay_evidence.json."""
+    import npy_replay as R
+    from locomanipulationrl_amd.engine_config import loco_cc_params, loco_params, mani_cc_params, mani_params
+    for name, ep in (("ground", loco_params()), ("plate", mani_params()), ("ground, PD actuator", loco_cc_params()), ("plate, PD actuator", mani_cc_params())):
+        e = R.sweep_convergence(robot_model, ep, [ep.pgs_iters], N=64, steps=16)[ep.pgs_iters]
+        assert len(e) > 100 and np.median(e) <= 0.01 and np.percentile(e, 90) <= 0.20, (name, ep.pgs_iters, np.median(e), np.percentile(e, 90))
+    e = R.sweep_convergence(robot_model, loco_params(), [4], N=64, steps=16)[4]
+    assert np.median(e) > 0.02 and np.percentile(e, 90) > 0.20
+
+
 def test_effort_and_position_control_modes(robot_model):
     """RobotOmni.take_action's other two control modes (robot/base/robot.py:444-461), golden = the reference's own scaling
     (tests/golden/take_action.npz).  Effort: the generalised force the oracle applies to the 12 driven joints is exactly the golden effort
