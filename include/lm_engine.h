@@ -118,7 +118,10 @@ typedef struct lm_params {
 
 typedef struct lm_engine lm_engine;   /* opaque */
 
-/* Pointers the host side may wrap zero-copy. */
+/* Pointers the host side may wrap zero-copy.  LM_PTR_OBS_BUF, LM_PTR_STATES_BUF and LM_PTR_TERMS are the engine's own unclipped copies of
+ * what lm_step's out_obs / out_states deliver clipped: lm_step keeps each of them current from the first lm_ptr() call for it on (ask before
+ * the step whose values you want), and in any case when the matching out_* argument is NULL; a caller that only consumes the out_* buffers
+ * does not pay for the second copy.  The staged entry points (lm_post_physics ...) always write them. */
 typedef enum {
   LM_PTR_STATE = 0,     /* float [LM_STATE_ROWS][N]                                  */
   LM_PTR_CNT = 1,       /* int64 [LM_CNT_ROWS][N]: successes, consecutive_successes,
@@ -153,7 +156,7 @@ int lm_destroy(lm_engine* h);
  * sub-steps, observations / reward / termination.  (vec_env_rlgames.py:56-79)
  *   actions     device float [N][12]
  *   goal_rand   device float [N][3] uniforms for goal sampling, or NULL for the in-kernel hash RNG
- *   out_*       device buffers receiving clipped copies for the caller (any may be NULL):
+ *   out_*       device buffers receiving clipped copies for the caller (any may be NULL; see lm_ptr_kind for the unclipped copies):
  *               obs [N][lm_num_obs], states [N][93], rew [N], resets int64 [N], extras float [LM_NUM_EXTRAS]
  *   stream      hipStream_t (void* here so the header needs no HIP include)
  * With params.dr_enabled the same launch also applies the action noise (before the clamp), samples this step's physics attributes

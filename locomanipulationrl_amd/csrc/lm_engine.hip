@@ -102,6 +102,7 @@ struct lm_engine {
   float* d_table;
   float* d_state; int64_t* d_cnt; int64_t* d_drc; float* d_dr_phys; int dr_enabled;
   float *d_obs, *d_states, *d_rew, *d_extras, *d_terms; long long* d_acc; int acc_rows;
+  bool view_obs, view_states, view_terms;      // lm_ptr() handed out obs_buf / states_buf / the reward terms: lm_step keeps them current from then on
   char* d_stats;           // int64 {num_successes, num_resets} x {all, first task, second task}; float success_rate x 3 at byte 48;
                            // uint32 count of contained blow-ups at byte 60
   lm_params h_params[2];
@@ -1015,10 +1016,22 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     for (int k = 0; k < KS; k++) { const int i = lane + 64 * k; vs[k] = reinterpret_cast<const float4*>(sSt)[(NS % 64 == 0 || i < NS) ? i : 0]; }
     float4* ob = reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NB); float4* oo = reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NB);
     float4* sb = reinterpret_cast<float4*>(W.states_buf + (size_t)env0 * 93); float4* so = reinterpret_cast<float4*>(W.out_states + (size_t)env0 * 93);
+    if (W.out_obs) {
 #pragma unroll
-    for (int k = 0; k < KV; k++) { const int i = lane + 64 * k; if (NV % 64 == 0 || i < NV) { ob[i] = vo[k]; if (W.out_obs) oo[i] = clamp4(vo[k]); } }
+      for (int k = 0; k < KV; k++) { const int i = lane + 64 * k; if (NV % 64 == 0 || i < NV) oo[i] = clamp4(vo[k]); }
+    }
+    if (W.out_states) {
 #pragma unroll
-    for (int k = 0; k < KS; k++) { const int i = lane + 64 * k; if (NS % 64 == 0 || i < NS) { sb[i] = vs[k]; if (W.out_states) so[i] = clamp4(vs[k]); } }
+      for (int k = 0; k < KS; k++) { const int i = lane + 64 * k; if (NS % 64 == 0 || i < NS) so[i] = clamp4(vs[k]); }
+    }
+    if (W.obs_buf) {
+#pragma unroll
+      for (int k = 0; k < KV; k++) { const int i = lane + 64 * k; if (NV % 64 == 0 || i < NV) ob[i] = vo[k]; }
+    }
+    if (W.states_buf) {
+#pragma unroll
+      for (int k = 0; k < KS; k++) { const int i = lane + 64 * k; if (NS % 64 == 0 || i < NS) sb[i] = vs[k]; }
+    }
   } else {
   // obs: nenv*NO floats contiguous (NO = 64 or 88, both multiples of 4)
   for (int i = lane; i < nenv * (NO / 4); i += 64) {
@@ -1036,20 +1049,20 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
       }
       v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
     }
-    reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NO)[i] = v;
+    if (W.obs_buf) reinterpret_cast<float4*>(W.obs_buf + (size_t)env0 * NO)[i] = v;
     if (W.out_obs) reinterpret_cast<float4*>(W.out_obs + (size_t)env0 * NO)[i] = clamp4(v);
   }
   // states: 16 rows of 93 floats are one contiguous block of 372 float4 (env0 is a multiple of 16: 5952-byte offsets)
   if (full) {
     for (int i = lane; i < ENVS_PER_WAVE * 93 / 4; i += 64) {
       float4 v = reinterpret_cast<const float4*>(sSt)[i];
-      reinterpret_cast<float4*>(W.states_buf + (size_t)env0 * 93)[i] = v;
+      if (W.states_buf) reinterpret_cast<float4*>(W.states_buf + (size_t)env0 * 93)[i] = v;
       if (W.out_states) reinterpret_cast<float4*>(W.out_states + (size_t)env0 * 93)[i] = clamp4(v);
     }
   } else {
     for (int i = lane; i < nenv * 93; i += 64) {
       float v = sSt[i];
-      W.states_buf[(size_t)env0 * 93 + i] = v;
+      if (W.states_buf) W.states_buf[(size_t)env0 * 93 + i] = v;
       if (W.out_states) W.out_states[(size_t)env0 * 93 + i] = clampf(v, clip);
     }
   }
@@ -1060,8 +1073,10 @@ LM_DEV void write_outputs(const lm_params* __restrict__ P, const OutPtrs& W, int
     if (W.out_resets) W.out_resets[env] = (int64_t)S.reset;
     cnt[0 * (size_t)N + env] = S.succ; cnt[1 * (size_t)N + env] = S.consec; cnt[2 * (size_t)N + env] = S.greset;
     cnt[3 * (size_t)N + env] = S.reset; cnt[4 * (size_t)N + env] = S.progress; cnt[5 * (size_t)N + env] = episode;
+    if (W.terms) {
 #pragma unroll
-    for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
+      for (int k = 0; k < 11; k++) W.terms[(size_t)k * N + env] = O.terms[k];
+    }
   }
   LM_STAMP(9);      // partial sums, atomics issued, output stores issued
   if (!DEFER) {
@@ -1915,6 +1930,15 @@ static StepArgs make_args(lm_engine* h, const float* actions, const float* goal_
   return A;
 }
 
+// The engine's own unclipped buffers (task.obs_buf / states_buf, rl_task.py:104-113, and the per-env reward terms) are a second copy of
+// what the caller's out_obs / out_states receive clipped: a step writes them only once somebody has asked lm_ptr() for them (the Python
+// task does, at construction), or when the caller passes no output buffer of that kind.  628 + 44 B per env-step of stores otherwise.
+static void drop_unrequested_views(const lm_engine* h, StepArgs& A) {
+  if (!h->view_obs && A.W.out_obs) A.W.obs_buf = nullptr;
+  if (!h->view_states && A.W.out_states) A.W.states_buf = nullptr;
+  if (!h->view_terms) A.W.terms = nullptr;
+}
+
 #ifdef LM_STAMPS
 extern "C" int lm_debug_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(lm_stamp_out), sizeof(lm_stamp_out)) == hipSuccess ? 0 : -1; }
 #endif
@@ -1925,6 +1949,7 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
   CHECK_DEVICE(h, "lm_step");
   hipStream_t s = (hipStream_t)stream;
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
+  drop_unrequested_views(h, A);
   const bool pd = A.kind[0] >= 2;                                  // both blocks are of one actuator family (lm_create)
   void (*kern)(StepArgs) = h->dr_enabled ? (pd ? k_step_dr_pd : k_step_dr) : (pd ? k_step_pd : k_step);
   hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(64), 0, s, A);
@@ -2011,12 +2036,12 @@ void* lm_ptr(lm_engine* h, int kind) {
     case LM_PTR_CNT: return h->d_cnt;
     case LM_PTR_DR_CNT: return h->d_drc;
     case LM_PTR_DR_PHYS: return h->d_dr_phys;
-    case LM_PTR_OBS_BUF: return h->d_obs;
-    case LM_PTR_STATES_BUF: return h->d_states;
+    case LM_PTR_OBS_BUF: h->view_obs = true; return h->d_obs;
+    case LM_PTR_STATES_BUF: h->view_states = true; return h->d_states;
     case LM_PTR_REW_BUF: return h->d_rew;
     case LM_PTR_EXTRAS: return h->d_extras;
     case LM_PTR_STATS: return h->d_stats;
-    case LM_PTR_TERMS: return h->d_terms;
+    case LM_PTR_TERMS: h->view_terms = true; return h->d_terms;
     default: return nullptr;
   }
 }
@@ -2032,6 +2057,8 @@ int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStr
   if (h->dr_enabled || R.nobs != h->num_obs) return fail(-1, "persistent rollout: domain-randomised engines and foreign observation widths run through the graph mode");
   if (!on_device(h)) return fail(-1, "persistent rollout: the calling thread's current device is not the engine's device");
   StepArgs A = make_args(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (!h->view_obs) A.W.obs_buf = nullptr;           // as the graph mode's lm_step(out_obs = the rollout's slot, out_states = NULL) does
+  if (!h->view_terms) A.W.terms = nullptr;
   RolloutDev D; D.params = R.params; D.log_std = R.log_std; D.obs = R.obs; D.actions = R.actions; D.logp = R.logp; D.values = R.values;
   D.rewards = R.rewards; D.dones = R.dones; D.acc_steps = R.acc_steps; D.T = R.T; D.noise_seed = R.noise_seed;
   static const bool streaming = getenv("LM_ROLLOUT_STREAMING_MLP") != nullptr;      // kernel experiments: the four-wavefront tile with streamed weights
@@ -2050,5 +2077,7 @@ int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs) {
   return (policy == LM_POLICY_MLP && (nobs == 64 || nobs == LM_MAX_OBS)) || (policy == LM_POLICY_GNN && nobs == 64);
 }
 
-uint32_t lm_internal_seed(const lm_engine* h) { return h ? h->seed : 0u; }
+uint64_t lm_internal_args_key(const lm_engine* h) {
+  return h ? ((uint64_t)h->seed | ((uint64_t)((h->view_obs ? 1 : 0) | (h->view_states ? 2 : 0) | (h->view_terms ? 4 : 0)) << 32)) : 0ull;
+}
 int lm_internal_fail(int code, const char* msg) { return fail(code, msg); }

@@ -18,7 +18,8 @@ struct LmRolloutArgs {
 int lm_internal_rollout(lm_engine* h, int policy, const LmRolloutArgs& R, hipStream_t s);
 // 1 when lm_internal_rollout can run this engine / policy / observation width
 int lm_internal_rollout_supported(const lm_engine* h, int policy, int nobs);
-// the engine's current goal / domain-randomisation seed (lm_set_seed changes it; a captured hipGraph holds the value it was captured with)
-uint32_t lm_internal_seed(const lm_engine* h);
+// what a captured lm_step launch has baked into its kernel arguments and the engine may change afterwards: the goal / domain-randomisation seed
+// (lm_set_seed) and which of the unclipped views are kept current (lm_ptr).  A hipGraph captured under another key is re-captured.
+uint64_t lm_internal_args_key(const lm_engine* h);
 // records a message for lm_last_error() (thread-local, lm_engine.hip) and returns `code`
 int lm_internal_fail(int code, const char* msg);

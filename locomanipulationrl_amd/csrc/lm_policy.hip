@@ -114,7 +114,7 @@ struct lm_rollout {
   float* mean_tmp; const int64_t* cnt; long long* acc_steps;      // acc_steps: [T][16] accumulators of the persistent kernel
   int n_cu; bool persistent_ok;                                   // compute units of the device; engine can run the persistent kernel
   hipGraphExec_t exec; hipStream_t exec_stream;
-  uint32_t exec_env_seed;                                         // engine seed baked into the captured kernel arguments
+  uint64_t exec_env_key;                                          // engine seed + requested views baked into the captured kernel arguments
 };
 
 static int rollout_enqueue(lm_rollout* r, hipStream_t s) {
@@ -178,12 +178,12 @@ int lm_rollout_run(lm_rollout* r, int use_graph, void* stream) {
     R.rewards = r->rewards; R.extras = r->extras; R.dones = r->dones; R.acc_steps = r->acc_steps; R.T = r->T; R.nobs = r->nobs; R.noise_seed = r->seed;
     return lm_internal_rollout(r->env, r->policy, R, s);
   }
-  if (r->exec && r->exec_env_seed != lm_internal_seed(r->env)) {      // lm_set_seed since the capture: the graph's kernel arguments hold the old seed
+  if (r->exec && r->exec_env_key != lm_internal_args_key(r->env)) {      // lm_set_seed / a first lm_ptr() for a view since the capture: the graph's kernel arguments are stale
     (void)hipGraphExecDestroy(r->exec); r->exec = nullptr;
   }
   if (!r->exec) {
     // capture the 4T+1 launches once; every pointer in them is fixed for the lifetime of the plan
-    r->exec_env_seed = lm_internal_seed(r->env);
+    r->exec_env_key = lm_internal_args_key(r->env);
     hipGraph_t g = nullptr;
     hipStream_t cs = s;
     bool own = false;

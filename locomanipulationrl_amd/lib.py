@@ -219,15 +219,33 @@ class Engine:
         self.state = self._wrap(PTR_STATE, (STATE_ROWS, N), "<f4")
         self.cnt = self._wrap(PTR_CNT, (CNT_ROWS, N), "<i8")
         self.num_obs = int(self.lib.lm_num_obs(self._h))
-        self.obs_buf = self._wrap(PTR_OBS_BUF, (N, self.num_obs), "<f4")
-        self.states_buf = self._wrap(PTR_STATES_BUF, (N, NUM_STATES), "<f4")
+        self._views = {}            # obs_buf / states_buf / terms: asked for on first access (lm_step writes them only from then on)
         self.rew_buf = self._wrap(PTR_REW_BUF, (N,), "<f4")
         self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
-        self.terms = self._wrap(PTR_TERMS, (TERM_ROWS, N), "<f4")
         self.stats_i64 = self._wrap(PTR_STATS, (6,), "<i8")
         self._stats_i32 = self._wrap(PTR_STATS, (16,), "<i4")         # word 15: contained blow-ups
         self.dr_cnt = self._wrap(PTR_DR_CNT, (5, N), "<i8")          # domain-randomisation counters
         self.dr_phys = self._wrap(PTR_DR_PHYS, (42, N), "<f4")       # attributes sampled for the last step
+
+    def _view(self, kind, shape):
+        if kind not in self._views:
+            self._views[kind] = self._wrap(kind, shape, "<f4")
+        return self._views[kind]
+
+    # The engine's own unclipped copies of what step() hands out clipped (task.obs_buf / states_buf of rl_task.py:104-113, the per-env reward
+    # terms).  lm_step keeps one current only after its pointer has been asked for (lm_ptr), or when step() is called without the matching
+    # output tensor: a caller that consumes out_obs / out_states alone does not pay for the second copy (672 B per env-step of stores).
+    @property
+    def obs_buf(self):
+        return self._view(PTR_OBS_BUF, (self.num_envs, self.num_obs))
+
+    @property
+    def states_buf(self):
+        return self._view(PTR_STATES_BUF, (self.num_envs, NUM_STATES))
+
+    @property
+    def terms(self):
+        return self._view(PTR_TERMS, (TERM_ROWS, self.num_envs))
 
     @property
     def blowups(self) -> int:

@@ -36,6 +36,7 @@ def test_config3_manipulation_4096():
     N = 4096
     env = lm.make_env("QuadrupedManipulatePlate", num_envs=N, seed=42)
     env.reset(); task = env._task
+    task.engine.terms                                   # ask for the per-env reward terms: the engine writes them from now on (include/lm_engine.h, lm_ptr_kind)
     g = torch.Generator(device="cuda").manual_seed(42)
     total = 0
     for t in range(300):
@@ -61,6 +62,7 @@ def test_config4_cotrain_block_2048_2048():
     N = 4096; h = N // 2
     env = lm.make_env("JointLocomanipulation", num_envs=N, seed=42)
     obs = env.reset(); task = env._task
+    task.engine.terms                                   # ask for the per-env reward terms
     assert obs["obs"].shape == (N, 64) and obs["states"].data_ptr() == obs["obs"].data_ptr()   # states alias obs (joint_locomanipulation.py:548)
     g = torch.Generator(device="cuda").manual_seed(7)
     res_l = res_m = 0
@@ -129,7 +131,7 @@ def test_extras_reduction_beyond_131040_wavefronts():
     N = 2_100_010                                       # not a multiple of 16: the last wavefront is ragged too
     ep = loco_params(); eng = Engine(load_model("quadruped_robot_v2"), [ep], N, seed=3)
     g = torch.Generator(device="cuda").manual_seed(3)
-    ex = torch.empty(13, device="cuda")
+    ex = torch.empty(13, device="cuda"); eng.terms      # (asked for before the steps whose values are read)
     ns = nr = 0
     for t in range(4):
         a = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1

@@ -248,6 +248,7 @@ def test_reference_npy_replay_hip(robot_model, recordings, oracle_runs):
     for name in R.FILES:
         kind = R.kind_of(name)
         eng = Engine(robot_model, [R.cotrain_params("loco"), R.cotrain_params("mani")], 32, split_env=16, seed=0)
+        eng.obs_buf                                          # the unclipped observations are read below: ask for them before the first step
         e0 = 0 if kind == "loco" else 16
         out_obs = torch.empty(32, 64, device="cuda"); out_rew = torch.empty(32, device="cuda")
 
