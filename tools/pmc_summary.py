@@ -35,7 +35,7 @@ if __name__ == "__main__":
             "per_wave": pw,
             "per_launch": {"fetch_bytes": fetch, "write_bytes": write, "hbm_traffic_bytes": fetch + write,
                            "note": "fetch_bytes = FETCH_SIZE x 2 (the gfx950 correction, checked for 4 B/lane loads in profiles/r02_fetch_calib.json); "
-                                   "writes include the unclipped obs_buf/states_buf copies the API exposes (+628 B/env) and the per-env reward terms (+44 B/env)"},
+                                   "the bench consumes the clipped out_* buffers only, so the engine's unclipped obs_buf / states_buf / reward-term copies (+672 B/env, written once lm_ptr() has handed them out) are not in these writes; algorithmic bytes: 1488 B/env-step x the envs of a launch"},
             "wave": {"valu_instructions": round(vi, 1), "wave_quad_cycles": round(wc, 1), "wait_quad_cycles": round(wa, 1),
                      "valu_issue_fraction": round(vi / wc, 4) if wc else None, "wait_fraction": round(wa / wc, 4) if wc else None,
                      "note": "one wavefront per SIMD: a VALU instruction occupies one quad-cycle issue slot, so valu_issue_fraction is the share of the "
