@@ -298,7 +298,7 @@ def main():
                        "vec_env_step_env_steps_per_s": vec_rate,
                        "zero_action_env_steps_per_s_rank0": zero_rate,
                        "mlp_policy_in_loop_env_steps_per_s_rank0": mlp_rate, **extra_rates,
-                       "drive_limit_reading": "max effort 1.5 read as PhysX's per-step impulse limit (never binds); parity unpinned, the torque-clamp reading is timed beside it",
+                       "drive_limit_reading": "max effort 1.5 read as an impulse limit (never binds on sustained loads; DESIGN.md 2.2: row 0 of the reference's recordings shows PhysX limiting the drive impulse per solver iteration); the 1.5 N m torque-clamp reading is timed beside it",
                        "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step",
