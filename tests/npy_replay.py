@@ -131,3 +131,36 @@ def sweep_convergence(robot_model, ep, counts, N=128, steps=24, every=4, seed=0)
         for k in counts:
             acc[k].append(np.linalg.norm(res[k] - res[128], axis=1)[m] / den[m])
     return {k: np.concatenate(v) for k, v in acc.items()}
+
+
+def pd_actuator_trajectories(robot_model, ep0, scheme, K, targets):
+    """The PD-actuator law  tau = clamp(kp (q* - q) - kd qd, +-max_effort)  of the custom-controller tasks under three discretisations, same scene,
+    same joint position targets (targets: (steps, N, 12), one row per control step); returns the joint positions after every control step.
+      "explicit"   the reference's own scheme (quadruped_pose_control_custom_controller.py:289-293): the torque is evaluated on the state before the
+                   sub-step and held over it (the oracle's effort mode with that torque; viscous joint damping added explicitly)
+      "implicit"   the shipped scheme: joints outside the limit by the pre-step torque get the limit torque, the others the law
+                   with the end-of-step velocity; "implicit2" = with pd_second_pass
+    K divides the sub-step: "explicit" at K = 16 stands for the continuous-time actuator both schemes discretise."""
+    from dataclasses import replace
+    from oracle.lmo import Oracle
+    kp, kd, cj, tm = ep0.pd_kp, ep0.kd, ep0.joint_damping, ep0.tau_max
+    if scheme == "explicit":
+        ep = replace(ep0, variant=0, num_obs=64, drive_mode=2, dt=ep0.dt / K, substeps=ep0.substeps * K, tau_max=1e9, act_scale=1.0, kd=100.0)
+    else:
+        ep = replace(ep0, dt=ep0.dt / K, substeps=ep0.substeps * K, pd_second_pass=1 if scheme == "implicit2" else 0)
+    o = Oracle(robot_model, ep); phys, _, _ = Oracle(robot_model, ep0).new_state(targets.shape[1]); out = []
+    for qs in targets:
+        for _ in range(ep.substeps):
+            q, qd = phys[:, 13:25], phys[:, 25:37]
+            o.substep(phys, (np.clip(kp * (qs - q) - kd * qd, -tm, tm) - cj * qd) if scheme == "explicit" else kp / kd * (qs - q))
+        out.append(phys[:, 13:25].copy())
+    return np.array(out)
+
+
+def pd_targets(robot_model, ep0, N, steps, seed=1):
+    """A random walk of joint position targets, 0.1 rad per control step as the task's action scale allows, within 0.6 rad of the reset pose."""
+    from oracle.lmo import Oracle
+    rng = np.random.default_rng(seed); ph, _, _ = Oracle(robot_model, ep0).new_state(N); q0 = ph[:, 13:25].copy(); q = q0.copy(); tg = []
+    for _ in range(steps):
+        q = np.clip(q + 0.1 * rng.uniform(-1, 1, (N, 12)), q0 - 0.6, q0 + 0.6); tg.append(q.copy())
+    return np.array(tg)

@@ -19,6 +19,8 @@ Tables
   row0_subiterated   the plate scene's row 0 with the drive limit clamped per solver iteration (K sub-iterations per step): PhysX's 16 reproduces its deflection
   convergence relative error of one sub-step's contact velocity change against the 128-sweep solve, per surface / actuator family and sweep count
               (states from random-action rollouts): the criterion behind engine_config.PGS_ITERS_* (median <= 1 %, 90th percentile <= 20 %, at least 4 sweeps)
+  pd_actuator the custom-controller tasks' PD actuator under the reference's explicit per-sub-step scheme and the shipped implicit one, against the
+              explicit scheme at dt / 16 (the continuous-time law): joint-position error over 40 control steps of random-walk targets
   files       the per-file outcome of the shipped specification
   link_clearance   how close the (unmodelled) link hulls come to the ground / the plate before a reset fires
 """
@@ -128,6 +130,16 @@ def main():
         for k, e in conv.items():
             row = dict(case=label, pgs_iters=k, shipped=bool(k == ep.pgs_iters), envs=int(len(e)), median=round(float(np.median(e)), 4), p90=round(float(np.percentile(e, 90)), 4), p99=round(float(np.percentile(e, 99)), 4))
             doc["convergence"].append(row); print(row, flush=True)
+    print("== the PD actuator of the custom-controller tasks: discretisations against the explicit law at dt / 16")
+    doc["pd_actuator"] = []
+    for label, ep in (("custom-controller locomotion", loco_cc_params()), ("custom-controller manipulation", mani_cc_params())):
+        tg = R.pd_targets(rm, ep, N=32, steps=40); truth = R.pd_actuator_trajectories(rm, ep, "explicit", 16, tg)
+        for sch, K, name in (("explicit", 1, "the reference's explicit scheme at dt"), ("explicit", 4, "explicit at dt / 4"), ("implicit", 1, "implicit, clamp decided pre-step (shipped)"),
+                             ("implicit2", 1, "shipped + pd_second_pass"), ("implicit", 4, "shipped scheme at dt / 4")):
+            tr = R.pd_actuator_trajectories(rm, ep, sch, K, tg); e = np.abs(tr - truth); ok = np.isfinite(e).all(axis=(0, 2))
+            row = dict(task=label, scheme=name, rms_rad=round(float(np.sqrt((e[:, ok] ** 2).mean())), 4), p99_rad=round(float(np.percentile(e[:, ok], 99)), 4),
+                       max_rad=round(float(e[:, ok].max()), 3), envs_finite=int(ok.sum()), envs=int(len(ok)))
+            doc["pd_actuator"].append(row); print(row, flush=True)
     print("== per file (shipped specification; replays held still for up to 2 rows after the recording to let a late streak complete)")
     doc["files"] = []
     runs = run(rm, rec, until_done=False); held = run(rm, rec, R.GOAL_KNOWN, until_done=True)

@@ -159,6 +159,23 @@ def test_pd_actuator_clamp_follows_the_reference_rule(robot_model):
             assert 0 < n_over <= 1e-3 * n and worst < ep.tau_max + ep.kd * 2 * ep.max_joint_vel, (n_over / n, worst)      # the excess is the implicit damping of one sub-step's velocity change
 
 
+def test_pd_actuator_scheme_follows_the_continuous_law(robot_model):
+    """The custom-controller tasks' actuator.  The reference evaluates  clamp(kp (q* - q) - kd qd)  explicitly per sub-step; at its
+    own dt = 0.005 that discretisation is far from the law it stands for (kd dt / I is of order 1 on these light links): against the same explicit
+    scheme at dt / 16 - the continuous-time actuator - it is off by tenths of a radian within a second, the shipped implicit form by a hundredth.
+    The shipped scheme is therefore pinned to the fine-step explicit law, not to the reference's coarse one."""
+    import npy_replay as R
+    from locomanipulationrl_amd.engine_config import loco_cc_params
+    ep = loco_cc_params(); tg = R.pd_targets(robot_model, ep, N=8, steps=16)
+    truth = R.pd_actuator_trajectories(robot_model, ep, "explicit", 16, tg)
+    shipped = R.pd_actuator_trajectories(robot_model, ep, "implicit", 1, tg)
+    coarse = R.pd_actuator_trajectories(robot_model, ep, "explicit", 1, tg)
+    rms = lambda a: float(np.sqrt(np.nanmean((a - truth) ** 2)))
+    assert np.isfinite(truth).all() and np.isfinite(shipped).all()
+    assert rms(shipped) < 0.02 and np.abs(shipped - truth).max() < 0.15, (rms(shipped), np.abs(shipped - truth).max())
+    assert (not np.isfinite(coarse).all()) or rms(coarse) > 5 * rms(shipped), (rms(coarse), rms(shipped))
+
+
 def test_shipped_sweep_counts_meet_the_convergence_criterion(robot_model):
     """engine_config.PGS_ITERS_*: the contact velocity change of a sub-step is within 1 % (median) / 20 % (90th percentile) of the 128-sweep
     solve's with the shipped counts - 8 on the ground under the rigid velocity drives, 4 on the plate and for the soft PD actuators - and
