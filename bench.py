@@ -17,7 +17,7 @@ the zero-action protocol of SURVEY 8(d), the same envs with the reference's MLP 
 48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`), the headline workload under the OTHER reading of the drive
 limit (`config.torque_clamp_reading_env_steps_per_s`: max effort 1.5 as a 1.5 N m torque clamp; the default reads it as PhysX's per-step
 impulse limit - parity unpinned), BASELINE config 3 and config 4's per-GPU block (`config.manipulation_...`,
-`config.cotrain_block_...`) and one PD-actuator task family (`config.pd_family_...`).
+`config.cotrain_block_...`), one PD-actuator task family (`config.pd_family_...`) and BASELINE config 5 (`config.config5_...`: vertical co-training, 8192 envs, GNN in the loop).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts `torch.distributed.run` with N ranks as a child BEFORE
 touching the GPU and exits with its code.
@@ -285,6 +285,24 @@ def main():
                                                           mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], split=N // 2),
                 "pd_family_env_steps_per_s": rate_of([loco_cc_params()], obs=88),
             }
+            # BASELINE config 5: the vertical co-training task, 8192 envs, the reference's GNN policy (random init, seed 42) in the loop --
+            # 48-step rollouts (GNN forward on fp32 MFMA -> sampling -> step) replayed as one hipGraph; rank 0, untimed region
+            from locomanipulationrl_amd.lib import POLICY_GNN
+            from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params
+            from locomanipulationrl_amd.utils.config import SimConfig, load_config
+            from locomanipulationrl_amd.utils.task_util import task_map
+            N5 = 8192; name5 = "JointLocomanipulationVertical"
+            t5 = task_map()[name5](name=name5, sim_config=SimConfig(load_config(name5, num_envs=N5)), env=None)
+            e5 = Engine(load_model(t5.model_asset), t5.engine_params(), N5, split_env=t5.split_env(), seed=42, device=str(dev))
+            torch.manual_seed(42); gm = GraphPolicy().to(dev)
+            o5 = torch.empty(N5, e5.num_obs, device=dev); e5.step(torch.zeros(N5, 12, device=dev), None, o5)
+            r5 = Rollout(e5, POLICY_GNN, pack_gnn_params(gm.net, gm.mean_layer, gm.value_layer).to(dev), torch.full((12,), -0.5, device=dev), ROLLOUT, noise_seed=42)
+            r5.obs[0] = o5
+            for _ in range(3): r5.run("auto"); r5.obs[0].copy_(r5.obs[ROLLOUT])
+            torch.cuda.synchronize(dev); t_ = time.perf_counter()
+            for _ in range(10): r5.run("auto"); r5.obs[0].copy_(r5.obs[ROLLOUT])
+            torch.cuda.synchronize(dev); extra_rates["config5_vertical_cotrain_8192_gnn_in_loop_env_steps_per_s"] = N5 * ROLLOUT * 10 / (time.perf_counter() - t_)
+            r5.close(); e5.close()
         result = {
             "metric": "env-steps/sec (whole node), horizontal-locomotion 4096 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
