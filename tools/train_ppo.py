@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--task", default="QuadrupedPoseControl"); ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--timesteps", type=int, default=4800); ap.add_argument("--policy", default="mlp"); ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--out", default=""); ap.add_argument("--log-every", type=int, default=5)
+    ap.add_argument("--randomize", action="store_true", help="switch the task YAML's domain_randomization block on (the reference's YAMLs ship it with randomize: False)")
     ap.add_argument("--fixed-lr", action="store_true", help="no KL-adaptive learning rate (diagnostics; not the reference recipe)")
     ap.add_argument("--gnn-env-order", action="store_true", help="diagnostic: route GNN node k's output to the joint whose state node k reads (the reference feeds node order straight to the env)")
     ap.add_argument("--no-obs-scaler", action="store_true", help="diagnostic: identity observation scaler")
@@ -30,7 +31,8 @@ def main():
     torch.cuda.set_device(local)
     rank, _, world = D.init_from_env(backend)
     torch.manual_seed(a.seed + rank)
-    env = lm.make_env(a.task, num_envs=a.num_envs, seed=a.seed, rank=rank, sim_device=f"cuda:{local}", rl_device=f"cuda:{local}")
+    env = lm.make_env(a.task, num_envs=a.num_envs, seed=a.seed, rank=rank, sim_device=f"cuda:{local}", rl_device=f"cuda:{local}",
+                      **({"overrides": {"task": {"domain_randomization": {"randomize": True}}}} if a.randomize else {}))
     if a.policy == "gnn":
         from locomanipulationrl_amd.policies.graph_model import GraphPolicy
         model = GraphPolicy().to(f"cuda:{local}"); hip = True
