@@ -912,7 +912,9 @@ struct OutPtrs { float *obs_buf, *states_buf, *rew_buf, *terms; float *out_obs, 
                  long long* acc;          // int64 [16 + acc_rows*16]: row 0 = totals of a launch, rows 1.. = the spread first-level rows (write_outputs);
                                           // the persistent rollout (DEFER) points it at one plain row of 14 fixed-point sums per step
                  char* stats; float* extras; float* out_extras; int split_block; int acc_rows; };
+#ifndef LM_ACC_COPIES
 #define LM_ACC_COPIES 32         // least number of first-level accumulator rows (lm_create doubles it until a row takes < 4096 wavefronts)
+#endif
 #define ACC_SCALE 1048576.0f      // 2^20: integer accumulation makes the means independent of the arrival order (bitwise reproducible)
 // Counted accumulator words (k_step): bits 0..11 count the arrivals, bits 12..63 hold the sum - a signed 2^20 fixed-point value for the
 // reward-term means (words 0..6, 9..11), two unsigned 26-bit counts (goal resets | resets) for the success-rate windows (word 7 all envs,
