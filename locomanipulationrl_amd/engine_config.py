@@ -170,12 +170,20 @@ class EngineParams:
     # reference's explicit clamp, ...custom_controller.py:289-293), one pass.  1: unsaturated joints whose implicit end-of-step torque left the limit
     # (0.02 % of the joint-sub-steps) are put on it too and the sub-step is solved again (+6 us per step at 4096 envs)
     pd_second_pass: int = 0
+    # ---- ORACLE-ONLY experiment of round 4 (oracle/lm_oracle.h `solver`): the drive rows inside the contact iteration, every drive
+    # row's impulse bounded per iteration by drive_iter_impulse (-1 = max_effort x dt).  The engine implements solver 0 only (lib.make_params refuses).
+    solver: int = 0
+    vel_iters: int = 0
+    drive_iter_impulse: float = -1.0
+    tgs_flags: int = 0
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
 
     def __post_init__(self):
         if self.tau_max < 0:
             self.tau_max = self.max_effort / self.dt if (self.drive_limits_are_impulses and self.dt > 0) else self.max_effort
+        if self.drive_iter_impulse < 0:
+            self.drive_iter_impulse = self.max_effort * self.dt
         if self.pgs_iters < 0:
             self.pgs_iters = PGS_ITERS_PD if self.variant != 0 else PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE
 

@@ -74,6 +74,8 @@ _DERIVED = {"plate_si", "plate_phi", "ctrl_dt_inv", "acc_dt_inv", "abi_version",
 
 def make_params(ep, clip_obs: float = 5.0, clip_actions: float = 1.0) -> LmParams:
     """EngineParams -> C struct (clipObservations / clipActions: QuadrupedPoseControl.yaml:11-12)."""
+    if getattr(ep, "solver", 0):
+        raise ValueError("EngineParams.solver != 0 is an oracle-only experiment (DESIGN.md 2.2): the engine implements solver 0")
     if getattr(ep, "pyramid", 0):
         raise ValueError("EngineParams.pyramid is an oracle-only evidence switch: the engine implements the friction cone only")
     p = LmParams()

@@ -309,16 +309,9 @@ static void chol_solve(real L[NU][NU], const real* b, real* x) {
 /* debug capture of the contact problem of the LAST pass executed (tests / solver studies) */
 static __thread real* g_cap_W = 0; static __thread real* g_cap_vf = 0; static __thread real* g_cap_bn = 0; static __thread real* g_cap_lam = 0;
 
-static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, const real* target, real* tau_out) {
-  dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t));
-  dyn_compute(m, p, phys, D);
-  const real dt=(real)p->dt, kd=(real)p->kd, tmax=(real)p->tau_max, mu=(real)p->mu, cj=(real)p->joint_damping;
-  real u[NU];
-  if (p->mode==0) { m3Tv(D->R0, phys+10, u); m3Tv(D->R0, phys+7, u+3); }
-  else { m3Tv(D->Rf, phys+47, u); m3Tv(D->Rf, phys+44, u+3); }
-  for (int j=0;j<12;j++) u[6+j]=phys[25+j];
-  /* contact geometry */
-  real Jc[12][NU], bn[4]; memset(Jc,0,sizeof(Jc));
+/* contact rows of one env: Jc[3i .. 3i+2] = (normal, t1, t2) rows of contact i with respect to u, phi[i] = signed gap */
+static void contact_rows(const lmo_params* p, const dyn_t* D, real Jc[12][NU], real* phi_out) {
+  memset(Jc,0,sizeof(real)*12*NU);
   for (int i=0;i<4;i++) {
     real n[3], t1[3], t2[3], phi; real Jrel[3][NU]; memcpy(Jrel, D->Jt[i], sizeof(Jrel));
     if (p->mode==0) {
@@ -345,6 +338,24 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     }
     for (int a=0;a<NU;a++) { real jn=0,j1=0,j2=0; for (int r=0;r<3;r++){ jn+=n[r]*Jrel[r][a]; j1+=t1[r]*Jrel[r][a]; j2+=t2[r]*Jrel[r][a]; }
       Jc[3*i][a]=jn; Jc[3*i+1][a]=j1; Jc[3*i+2][a]=j2; }
+    phi_out[i]=phi;
+  }
+}
+
+static void substep_tgs(const lmo_model* m, const lmo_params* p, real* phys, const real* target, real* tau_out);
+
+static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, const real* target, real* tau_out) {
+  if (p->solver==1 && p->variant==0 && p->drive_mode==0) { substep_tgs(m, p, phys, target, tau_out); return; }
+  dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t));
+  dyn_compute(m, p, phys, D);
+  const real dt=(real)p->dt, kd=(real)p->kd, tmax=(real)p->tau_max, mu=(real)p->mu, cj=(real)p->joint_damping;
+  real u[NU];
+  if (p->mode==0) { m3Tv(D->R0, phys+10, u); m3Tv(D->R0, phys+7, u+3); }
+  else { m3Tv(D->Rf, phys+47, u); m3Tv(D->Rf, phys+44, u+3); }
+  for (int j=0;j<12;j++) u[6+j]=phys[25+j];
+  /* contact geometry */
+  real Jc[12][NU], bn[4], phi4[4]; contact_rows(p, D, Jc, phi4);
+  for (int i=0;i<4;i++) { real phi=phi4[i];
     if (phi>=0) bn[i]=phi/dt; else { real b=(real)p->baumgarte*phi/dt; if (b<-(real)p->max_depen_vel) b=-(real)p->max_depen_vel; bn[i]=b; }
   }
   /* effort mode (robot.py:455-459): the action is the joint torque itself, gains off - the constant-torque branch of the drive from the start */
@@ -408,6 +419,106 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
     real Rn[9], vw[3]; quat_to_mat(quat, Rn); m3v(Rn, un+3, vw);
     for (int a=0;a<3;a++) { ang[a]=ww[a]; lin[a]=vw[a]; pos[a]+=dt*vw[a]; }
   }
+  free(D);
+}
+
+/* lmo_params.solver = 1 (round 4): the velocity drive as rows of the same iteration as the contacts, on one linearisation
+ * per sub-step.  Only numbers the reference holds: pgs_iters = solver_position_iteration_count 16 and vel_iters = solver_velocity_iteration_count 2
+ * (cfg/task/QuadrupedPoseControl.yaml:41-42), the per-iteration drive impulse max_effort x dt (robot/base/robot.py:347-355), the joint speed
+ * bound 450 deg/s (Design/Scripts/config_module_joints.py:11), max_depenetration_velocity 100 (YAML :50).  M is NOT augmented by the drive:
+ * a drive row is the damper  dP = h kd (v* - qd - W dP)  over the iteration's share h = dt / pgs_iters of the step. */
+static void advance_free(const real* Rf, real* pos, real* quat, const real* v, real h) {
+  real ww[3], vw[3]; m3v(Rf, v, ww); m3v(Rf, v+3, vw);
+  real th = sqrt(dot3(ww,ww))*h, dq[4];
+  if (th < (real)1e-8) { dq[0]=1; for (int a=0;a<3;a++) dq[1+a]=(real)0.5*h*ww[a]; }
+  else { real s=sin(th*(real)0.5)/(th/h); dq[0]=cos(th*(real)0.5); for (int a=0;a<3;a++) dq[1+a]=s*ww[a]; }
+  real qn[4]; quat_mul(dq, quat, qn); real nn=sqrt(qn[0]*qn[0]+qn[1]*qn[1]+qn[2]*qn[2]+qn[3]*qn[3]);
+  for (int a=0;a<4;a++) quat[a]=qn[a]/nn;
+  for (int a=0;a<3;a++) pos[a]+=h*vw[a];
+}
+
+static void substep_tgs(const lmo_model* m, const lmo_params* p, real* phys, const real* target, real* tau_out) {
+  dyn_t* D = (dyn_t*)malloc(sizeof(dyn_t));
+  dyn_compute(m, p, phys, D);
+  const int K = p->pgs_iters>0 ? p->pgs_iters : 1, F = p->tgs_flags;
+  const real dt=(real)p->dt, h=dt/(real)K, kd=(real)p->kd, mu=(real)p->mu, cj=(real)p->joint_damping;
+  real v[NU];
+  if (p->mode==0) { m3Tv(D->R0, phys+10, v); m3Tv(D->R0, phys+7, v+3); }
+  else { m3Tv(D->Rf, phys+47, v); m3Tv(D->Rf, phys+44, v+3); }
+  for (int j=0;j<12;j++) v[6+j]=phys[25+j];
+  real Jc[12][NU], phi[4]; contact_rows(p, D, Jc, phi);
+  real L[NU][NU]; memcpy(L, D->M, sizeof(L)); real rhs[NU], acc[NU];
+  for (int a=0;a<NU;a++) rhs[a]=-D->h[a];
+  for (int j=0;j<12;j++) { real cjj=g_dr?g_dr->cj[j]:cj; L[6+j][6+j]+=dt*cjj; rhs[6+j]-=cjj*v[6+j]; }
+  chol(L); chol_solve(L, rhs, acc); for (int a=0;a<NU;a++) v[a]+=dt*acc[a];      /* external forces over the whole step, once, before the iterations */
+  real MiJ[12][NU], MiD[12][NU], Wc[12], Wd[12], lam[12], P[12], dq[12];
+  for (int r=0;r<12;r++) { chol_solve(L, Jc[r], MiJ[r]); real s=0; for (int a=0;a<NU;a++) s+=Jc[r][a]*MiJ[r][a]; Wc[r]=s; lam[r]=0; }
+  for (int j=0;j<12;j++) { real e[NU]; memset(e,0,sizeof(e)); e[6+j]=1; chol_solve(L, e, MiD[j]); Wd[j]=MiD[j][6+j]; P[j]=0; dq[j]=0; }
+  real* pos  = (p->mode==0)? phys   : phys+37;
+  real* quat = (p->mode==0)? phys+3 : phys+40;
+  real* lin  = (p->mode==0)? phys+7 : phys+44;
+  real* ang  = (p->mode==0)? phys+10: phys+47;
+  const real lim0 = (real)p->drive_iter_impulse;
+  for (int it=0; it<K+p->vel_iters; it++) {
+    const int posit = it<K;
+    if (F&32) for (int r=0;r<12;r++) lam[r]=0;                  /* every iteration its own impulses (no release of an earlier iteration's push) */
+    for (int half=0; half<2; half++) {
+      const int drives = (F&1) ? (half==0) : (half==1);
+      if (!drives) {
+        for (int ii=0;ii<4;ii++) {
+          const int i=((it&1)&&!(F&256))?3-ii:ii, r=3*i;
+          if (phi[i]>(real)1e2) continue;                      /* off the plate */
+          real vn=0; for (int a=0;a<NU;a++) vn+=Jc[r][a]*v[a];
+          real b;
+          if (phi[i]>=0) b = phi[i]/((F&64) ? dt : (F&8) ? (dt-(real)(posit?it:K-1)*h) : h);          /* a gap may close, not more */
+          else if (posit) { b=(real)p->baumgarte*phi[i]/h; if (b<-(real)p->max_depen_vel) b=-(real)p->max_depen_vel; }
+          else b=0;                                                                   /* velocity iterations: no penetration bias */
+          real ln=lam[r]-(vn+b)/Wc[r]; if (ln<0) ln=0; real d=ln-lam[r]; lam[r]=ln;
+          for (int a=0;a<NU;a++) v[a]+=MiJ[r][a]*d;
+          real vt1=0, vt2=0; for (int a=0;a<NU;a++) { vt1+=Jc[r+1][a]*v[a]; vt2+=Jc[r+2][a]*v[a]; }
+          real l1=lam[r+1]-vt1/Wc[r+1], l2=lam[r+2]-vt2/Wc[r+2]; const real lm=mu*lam[r];
+          real n2=l1*l1+l2*l2; if (n2>lm*lm) { real sc=lm/sqrt(n2); l1*=sc; l2*=sc; }
+          real d1=l1-lam[r+1], d2=l2-lam[r+2]; lam[r+1]=l1; lam[r+2]=l2;
+          for (int a=0;a<NU;a++) v[a]+=MiJ[r+1][a]*d1+MiJ[r+2][a]*d2;
+        }
+      } else if (F&512) {
+        /* the 12 drive rows as ONE block: (I / (h kd) + W_dd) dP = v* - qd, solved exactly, then each row's impulse bounded */
+        real A[NU][NU], b12[NU], x[NU]; memset(A,0,sizeof(A)); memset(b12,0,sizeof(b12));
+        for (int j=0;j<12;j++) { for (int k=0;k<12;k++) A[j][k]=MiD[k][6+j]; A[j][j]+=1/(h*kd); b12[j]=target[j]-v[6+j]; }
+        for (int j=12;j<NU;j++) A[j][j]=1;
+        chol(A); chol_solve(A, b12, x);
+        for (int j=0;j<12;j++) { real lim = g_dr ? g_dr->tmax[j]*dt : lim0, dP=x[j];
+          if (lim>0) { if (dP>lim) dP=lim; if (dP<-lim) dP=-lim; }
+          P[j]+=dP; for (int a=0;a<NU;a++) v[a]+=MiD[j][a]*dP; }
+      } else {
+        for (int jj=0;jj<12;jj++) {
+          static const int limb_order[12]={0,4,5,1,6,7,2,8,9,3,10,11};
+          const int j=(F&128)?limb_order[jj]:jj;
+          real lim = g_dr ? g_dr->tmax[j]*dt : lim0;
+          real dP = h*kd*(target[j]-v[6+j])/(1+h*kd*Wd[j]);
+          if (lim>0) {
+            if (F&16) { real Pn=P[j]+dP, cap=lim*(real)K; if (Pn>cap) Pn=cap; if (Pn<-cap) Pn=-cap; dP=Pn-P[j]; }
+            else { if (dP>lim) dP=lim; if (dP<-lim) dP=-lim; }
+          }
+          P[j]+=dP; for (int a=0;a<NU;a++) v[a]+=MiD[j][a]*dP;
+        }
+      }
+    }
+    for (int j=0;j<12;j++) {                                    /* joint speed bound, every iteration */
+      real vm=g_dr?g_dr->vmax[j]:(real)p->max_joint_vel, x=v[6+j], c=x>vm?vm:(x<-vm?-vm:x);
+      if (c!=x) { if (F&4) { real dP=(c-x)/Wd[j]; for (int a=0;a<NU;a++) v[a]+=MiD[j][a]*dP; } else v[6+j]=c; }
+    }
+    if (posit && !(F&2)) {                                       /* TGS: gaps, joint angles and the free body advance by the iteration's share */
+      for (int i=0;i<4;i++) { real vn=0; for (int a=0;a<NU;a++) vn+=Jc[3*i][a]*v[a]; phi[i]+=h*vn; }
+      for (int j=0;j<12;j++) dq[j]+=h*v[6+j];
+      advance_free(D->Rf, pos, quat, v, h);
+    }
+  }
+  if (F&2) { for (int j=0;j<12;j++) dq[j]=dt*v[6+j]; advance_free(D->Rf, pos, quat, v, dt); }
+  if (tau_out) for (int j=0;j<12;j++) tau_out[j]=P[j]/dt;
+  for (int j=0;j<12;j++) { phys[25+j]=v[6+j]; phys[13+j]+=dq[j]; }
+  { real Rn[9], ww[3], vw[3]; m3v(D->Rf, v, ww); quat_to_mat(quat, Rn); m3v(Rn, v+3, vw);
+    for (int a=0;a<3;a++) { ang[a]=ww[a]; lin[a]=vw[a]; } }
   free(D);
 }
 

@@ -139,6 +139,24 @@ typedef struct {
   int32_t drive_mode;        /* variant 0: RobotOmni.take_action's control mode (robot/base/robot.py:444-461): 0 velocity target a*act_scale,
                                 1 position target a*act_scale with tau = pd_kp (q* - q) - kd qd per sub-step, 2 effort tau = a*act_scale */
   int32_t pd_second_pass;    /* variants 1 / 2: 1 = unsaturated joints whose implicit torque left the limit are put on it and the sub-step is solved again (engine_config.py) */
+  /* ---- round 4: the drive as rows of the SAME velocity-level iteration as the contacts (variant 0, velocity drive).
+   * solver 0 = the drive solved exactly (diagonal augmentation of M) and Gauss-Seidel on the contact rows only;
+   * solver 1 = `pgs_iters` position iterations (the reference's solver_position_iteration_count 16, cfg/task/QuadrupedPoseControl.yaml:41) over
+   * [4 contacts x (normal, friction pair), 12 drive rows] on ONE linearisation per sub-step, every drive row's impulse bounded PER ITERATION by
+   * drive_iter_impulse (max effort 1.5 N m x dt: robot/base/robot.py:347-355), joint speeds bounded by max_joint_vel in every iteration
+   * (Design/Scripts/config_module_joints.py:11), gaps and joint angles advanced by dt / pgs_iters after every iteration (TGS), then `vel_iters`
+   * iterations without the penetration bias (solver_velocity_iteration_count 2, YAML :42). */
+  int32_t solver;
+  int32_t vel_iters;
+  double drive_iter_impulse;   /* N m s per iteration and drive row; <= 0: unbounded */
+  int32_t tgs_flags;           /* experiment switches of solver 1 (tests/npy_replay_evidence.py): 1 = drive rows before the contact rows; 2 = positions advance
+                                  with the END velocity over the whole dt instead of per iteration; 4 = the speed bound as an impulse through M^-1 instead
+                                  of a direct clamp; 8 = a gap's speculative bias over the whole dt instead of the iteration's share;
+                                  16 = the drive's impulse bound on the accumulated impulse (x pgs_iters) instead of per iteration;
+                                  64 = a gap's speculative bias is (current gap) / dt;
+                                  128 = drive rows limb by limb (hip, dof2, dof3) instead of the DoF order; 256 = contacts always in limb order;
+                                  512 = the 12 drive rows solved as one block per iteration (exact 12 x 12 solve, then the per-row bound);
+                                  32 = contact impulses accumulate (and are clamped / released) within one iteration only */
 } lmo_params;
 
 /* per-env physical state, env-major */

@@ -61,6 +61,7 @@ class LmoParams(C.Structure):
         ("power_scale", C.c_double), ("target_err_scale", C.c_double), ("rot_dec_scale", C.c_double), ("rot_dec_thresh", C.c_double), ("cc_update_last_tgt", C.c_int32), ("acc_substeps", C.c_int32),
         ("dr_enabled", C.c_int32), ("dr_min_frequency", C.c_int32), ("dr", LmoDrChannel * 9),
         ("drive_mode", C.c_int32), ("pd_second_pass", C.c_int32),
+        ("solver", C.c_int32), ("vel_iters", C.c_int32), ("drive_iter_impulse", C.c_double), ("tgs_flags", C.c_int32),
     ]
 
 
@@ -108,6 +109,8 @@ def make_params(ep) -> LmoParams:
     for name, ctype in LmoParams._fields_:
         if name == "pyramid":
             p.pyramid = int(getattr(ep, "pyramid", 0)); continue
+        if name in ("solver", "vel_iters", "tgs_flags", "drive_iter_impulse"):            # oracle-only experiment of round 4
+            setattr(p, name, getattr(ep, name, 0)); continue
         if name == "dr":
             for i, ch in enumerate(ep.dr):
                 p.dr[i].enabled, p.dr[i].operation, p.dr[i].distribution, p.dr[i].interval = int(ch.enabled), int(ch.operation), int(ch.distribution), int(ch.interval)
