@@ -21,6 +21,9 @@ Tables
               (states from random-action rollouts): the criterion behind engine_config.PGS_ITERS_* (median <= 1 %, 90th percentile <= 20 %, at least 4 sweeps)
   pd_actuator the custom-controller tasks' PD actuator under the reference's explicit per-sub-step scheme and the shipped implicit one, against the
               explicit scheme at dt / 16 (the continuous-time law): joint-position error over 40 control steps of random-walk targets
+  leave_one_out   the friction coefficient chosen on any six of the seven goal-known episodes (most shared window rows), 64 and 8 sweeps; and fitted on
+              one kind, judged on the other
+  unconstrained   variants the recordings do NOT tell from the shipped specification (they pass every check): drive damping, drive limit >= 6 N m, Baumgarte
   files       the per-file outcome of the shipped specification
   link_clearance   how close the (unmodelled) link hulls come to the ground / the plate before a reset fires
 """
@@ -79,13 +82,35 @@ def main():
         for it in (8, 64):
             o = outcome(run(rm, rec, G, pgs_iters=it, mu=mu)); o.update(mu=mu, pgs_iters=it, shared=shared(o)); doc["friction"].append(o)
             print(f"cone mu {mu:4.2f} sweeps {it:3d}: {fmt(o)} | shared {o['shared']}", flush=True)
+    print("== leave-one-out choice of the friction coefficient (most shared rows on the other six episodes)")
+    import test_reference_npy_replay as T
+    doc["leave_one_out"] = []
+    for it in (64, 8):
+        tab = T.mu_table(rm, rec, it)
+        for name, mu, rows in T.leave_one_out(tab):
+            row = dict(pgs_iters=it, held_out=name, picked_mu=mu, held_out_rows_in_window=rows); doc["leave_one_out"].append(row); print(row, flush=True)
+        kinds = {k: [i for i, n in enumerate(R.GOAL_KNOWN) if R.kind_of(n) == k] for k in ("loco", "mani")}
+        for fit, held in (("loco", "mani"), ("mani", "loco")):
+            pick = max(T.MU_GRID, key=lambda m: sum(tab[m][i] for i in kinds[fit]))
+            row = dict(pgs_iters=it, fitted_on=fit, picked_mu=pick, rows_on_the_other_kind=int(sum(tab[pick][i] for i in kinds[held])),
+                       best_possible_on_the_other_kind=int(max(sum(tab[m][i] for i in kinds[held]) for m in T.MU_GRID)))
+            doc["leave_one_out"].append(row); print(row, flush=True)
+        doc.setdefault("mu_table", []).append(dict(pgs_iters=it, files=R.GOAL_KNOWN, rows_in_window={str(m): v for m, v in tab.items()}))
+    print("== what the recordings do not constrain (every check passes)")
+    doc["unconstrained"] = []
+    for label, kw in [("drive damping 50", dict(kd=50.0)), ("drive damping 200", dict(kd=200.0)), ("drive limit 6 N m", dict(tau_max=6.0)), ("drive limit 24 N m", dict(tau_max=24.0)),
+                      ("Baumgarte 0.5", dict(baumgarte=0.5)), ("1 sweep", dict(pgs_iters=1))]:
+        runs = run(rm, rec, G, **kw); o = outcome(runs); held = run(rm, rec, R.GOAL_KNOWN, until_done=True, **kw)
+        o.update(variant=label, shared=shared(o), orientation_checks=T.orientation_ok(runs), returns_in_bracket=int(sum(T.episode_reward(held[n])["ok"] for n in R.GOAL_KNOWN)))
+        doc["unconstrained"].append(o); print(f"{label:24s} {fmt(o)} | shared {o['shared']} orientation {'pass' if o['orientation_checks'] else 'FAIL'} returns {o['returns_in_bracket']}/7", flush=True)
     print("== negative controls and earlier specifications")
     doc["controls"] = []
-    for label, kw in [("shipped specification", {}), ("gravity 0", dict(gravity=0.0)), ("half gravity", dict(gravity=4.905)), ("friction 0", dict(mu=0.0)), ("friction doubled", dict(mu=1.6)),
+    for label, kw in [("shipped specification", {}), ("gravity 0", dict(gravity=0.0)), ("half gravity", dict(gravity=4.905)), ("gravity x 1.2", dict(gravity=11.772)), ("friction 0", dict(mu=0.0)), ("friction doubled", dict(mu=1.6)),
+                      ("mu 0.6", dict(mu=0.6)), ("nominal mu 1.0, 8 sweeps", dict(mu=1.0)), ("nominal mu 1.0, 64 sweeps", dict(mu=1.0, pgs_iters=64)), ("mu 0.9, 64 sweeps", dict(mu=0.9, pgs_iters=64)), ("10 mm foot", dict(tip_radius=0.010)),
                       ("friction pyramid of rounds 1-2 (8 sweeps, mu 1.0)", dict(pyramid=1, mu=1.0)), ("friction pyramid, 16 sweeps", dict(pyramid=1, mu=1.0, pgs_iters=16)),
                       ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5))]:
-        runs = run(rm, rec, **kw); o = outcome(runs); o.update(variant=label, joints=joint_stats(runs), shared=shared(o)); doc["controls"].append(o)
-        print(f"{label:50s} {fmt(o)} | shared {o['shared']}  joints {o['joints']}", flush=True)
+        runs = run(rm, rec, **kw); o = outcome(runs); o.update(variant=label, joints=joint_stats(runs), shared=shared(o), orientation_checks=T.orientation_ok(runs)); doc["controls"].append(o)
+        print(f"{label:50s} {fmt(o)} | shared {o['shared']} orientation {'pass' if o['orientation_checks'] else 'FAIL'}  joints {o['joints']}", flush=True)
     print("== readings of set_max_efforts(1.5): the joint-level statistics")
     doc["drive"] = []
     for label, kw in [("1.5 N m torque clamp", dict(tau_max=1.5)), ("2.0 N m (the USD's maxForce)", dict(tau_max=2.0)), ("3 N m", dict(tau_max=3.0)), ("6 N m", dict(tau_max=6.0)),

@@ -11,18 +11,26 @@ What each group of assertions does and does not prove (the contract):
       `test_joint_level_checks_are_a_drive_limit_test` keeps that on record).  Their negative control is the 1.5 N m torque clamp.
   ORIENTATION / TERMINATION CHECKS (the physics).  The base pose is not recorded; it is pinned through what the task computed from it:
       PhysX's rot_dist entered the 0.15 rad success window on row T - 17 of each of the seven goal-known episodes, stayed inside for 17
-      rows, and `test` ended in a fall on its last row.  Asserted PER KIND: locomotion >= 3 of 4 files enter the window (the shipped
-      specification: 4 of 4), manipulation 3 of 3, each within 3 rows of PhysX; at least 85 of PhysX's 7 x 17 window rows are shared (97);
-      every file gets from >= 0.75 rad to <= 0.26 rad; no file terminates before PhysX did except by the knee test within 3 rows of PhysX's
-      entry; `test` terminates on its recorded last row.
-      NEGATIVE CONTROLS THAT MUST FAIL these checks: gravity 0, half gravity, friction 0, friction doubled, the axis-aligned friction
-      pyramid of rounds 1-2, the 1.5 N m torque clamp, a 20 mm foot (the last one only through the fall row of `test`: the recordings
-      hardly constrain the foot radius).
+      rows, and `test` ended in a fall on its last row.  Asserted PER KIND, at what the shipped specification achieves (round 4: the thresholds
+      guard the outcome, they no longer sit below it): locomotion 4 of 4 files enter the window, manipulation 3 of 3, each within 2 rows of
+      PhysX's row except `mlp_joint_loco_from_mani` (named: 3 rows early, then ends on the knee test); at least 93 of PhysX's 7 x 17 window
+      rows are shared (97 by the fp64 oracle); every file gets from >= 0.75 rad to <= 0.26 rad; no file terminates before PhysX did except the
+      named one by the knee test within 3 rows of PhysX's entry; `test` terminates on its recorded last row.
+      NEGATIVE CONTROLS THAT MUST FAIL these checks: gravity 0, half gravity, gravity x 1.2, friction 0, friction doubled, mu 0.6, the nominal
+      mu 1.0 (at the shipped 8 sweeps and converged, 64 sweeps), mu 0.9 converged, the axis-aligned friction pyramid of rounds 1-2, the
+      1.5 N m torque clamp, a 20 mm and a 10 mm foot (the foot radii only through the fall row of `test`: the recordings hardly constrain it).
+      WHAT THE FIXTURES DO NOT CONSTRAIN (asserted too, so that nobody reads more into the test): drive damping 50 ... 200, a drive limit of
+      6 N m or more, Baumgarte 0.2 ... 0.5 pass every check (`test_what_the_recordings_do_not_constrain`).
+  THE FRICTION COEFFICIENT is fitted on these files (0.8 x nominal, parity unpinned); `test_friction_coefficient_leave_one_out` shows what
+      that fit is worth: chosen on any six of the seven episodes (most shared window rows, converged solve) it comes out at 0.8 in six of
+      seven folds (0.6 - tied with 0.75 and 0.8 - in the seventh), at the shipped 8 sweeps in seven of seven; chosen on the locomotion files alone
+      it is 0.8 and is the best coefficient for the manipulation files, and the other way round.
   EPISODE REWARD (north star: "joint states and episode reward").  PhysX's episode is 17 rows inside the window (rot reward
       0.5 / (rot_dist + 0.1) >= 2.0 each, quadruped_pose_control.py:428-462) and the 600 bonus on the last row.  The replay must end in
       success within 2 rows of PhysX's last row (held still after the recording for that long at most) and collect a return inside the
-      bracket PhysX's episode implies, for >= 2 of 4 locomotion and >= 2 of 3 manipulation files (shipped: 3 + 2, three of them on PhysX's
-      very row; the bonus is 94 % of the return: missing it is a 94 % error).
+      bracket PhysX's episode implies, for 5 of the 7 files - every file except the two named ones, `mlp_joint_loco_from_mani` (knee test on row
+      13) and `mlp_mani_from_loco` (leaves the window at 0.198 rad on its last row), whose miss of the bonus (94 % of the return) is the open
+      residual of the episode-reward parity.
   ROW 0 (one control period after reset, zero action).  PhysX's joints give way by 3e-3 ... 1.25e-2 rad (identical in every file); this
       engine's by 1e-4 ... 3e-4 in the SAME direction on every loaded joint.  The direction is asserted (a frozen robot fails it); the
       magnitude is a documented residual (reproduced only by a drive that yields at ~1.5 N m, which the later rows rule
@@ -87,6 +95,11 @@ def reached_by_kind(runs):
     return out
 
 
+EARLY_KNEE = "mlp_joint_loco_from_mani"        # enters 3 rows before PhysX, then trips the knee test (a link origin at 40 mm) 2 rows before PhysX's streak starts
+LATE_EXIT = "mlp_mani_from_loco"               # inside the window from row 14, out again at 0.198 rad on PhysX's last row
+SHARED_MIN = 93                                # of PhysX's 7 x 17 rows inside the success window (fp64 oracle: 97)
+
+
 def check_orientation(runs):
     t = runs["test"]
     assert t["done_at"] == t["T"] - 1 and not t["goal"], ("test", t["done_at"])
@@ -94,14 +107,14 @@ def check_orientation(runs):
         r = runs[name]
         assert r["rd"][0] >= 0.75 and r["rd_rec"].min() <= 0.26, (name, r["rd"][0], r["rd_rec"].min())
         if r["first_succ"] is not None:
-            assert abs(r["first_succ"] - r["succ_row"]) <= 3, (name, r["first_succ"], r["succ_row"])
+            assert abs(r["first_succ"] - r["succ_row"]) <= (3 if name == EARLY_KNEE else 2), (name, r["first_succ"], r["succ_row"])
         if r["done_at"] is not None and r["done_at"] < r["T"] - 1:
-            assert r["done_at"] >= r["succ_row"] - 3, (name, r["done_at"])
+            assert name == EARLY_KNEE and r["done_at"] >= r["succ_row"] - 3, (name, r["done_at"])
     n = reached_by_kind(runs)
-    assert n["loco"][0] >= 3 and n["loco"][1] == 4, n
-    assert n["mani"][0] == 3 and n["mani"][1] == 3, n
+    assert n["loco"] == [4, 4], n
+    assert n["mani"] == [3, 3], n
     shared = sum(runs[name]["in_window"] for name in R.GOAL_KNOWN)
-    assert shared >= 85, shared                                   # of PhysX's 7 x 17 rows inside the success window
+    assert shared >= SHARED_MIN, shared
 
 
 def orientation_ok(runs):
@@ -136,14 +149,15 @@ def episode_reward(r):
 
 
 def check_episode_reward(runs_until_done):
-    ok = {"loco": 0, "mani": 0}
+    ok = []
     for name in R.GOAL_KNOWN:
         r = runs_until_done[name]; e = episode_reward(r)
         print(f"{name:30s} return over PhysX's window rows + bonus {e['ret']:7.1f}  bracket [{e['lo']:.1f}, {e['hi']:.1f}]  bonus on row {e['bonus_row']} (PhysX {r['T'] - 1})")
         if e["ok"]:
             assert 0 <= e["bonus_row"] - (r["T"] - 1) <= 2, name            # on PhysX's last row or at most two rows later
-            ok[R.kind_of(name)] += 1
-    assert ok["loco"] >= 2 and ok["mani"] >= 2, ok
+            ok.append(name)
+    # 5 of 7: every episode except the two named ones collects PhysX's return (a regression to 4 of 7 fails; the two are the open residual)
+    assert set(R.GOAL_KNOWN) - set(ok) <= {EARLY_KNEE, LATE_EXIT}, sorted(set(R.GOAL_KNOWN) - set(ok))
 
 
 # ---------------------------------------------------------------------------------------------------------------- CPU oracle
@@ -157,16 +171,67 @@ def test_episode_reward_of_the_replays(robot_model, recordings):
     check_episode_reward(run_all(robot_model, recordings, files=R.GOAL_KNOWN, until_done=True))
 
 
-@pytest.mark.parametrize("label, kw", [("gravity 0", dict(gravity=0.0)), ("half gravity", dict(gravity=4.905)), ("friction 0", dict(mu=0.0)),
-                                       ("friction doubled", dict(mu=1.6)), ("friction pyramid of rounds 1-2 (8 sweeps, mu 1.0)", dict(pyramid=1, mu=1.0)),
+@pytest.mark.parametrize("label, kw", [("gravity 0", dict(gravity=0.0)), ("half gravity", dict(gravity=4.905)), ("gravity x 1.2", dict(gravity=11.772)), ("friction 0", dict(mu=0.0)),
+                                       ("friction doubled", dict(mu=1.6)), ("mu 0.6", dict(mu=0.6)), ("nominal mu 1.0, 8 sweeps", dict(mu=1.0)),
+                                       ("nominal mu 1.0, converged (64 sweeps)", dict(mu=1.0, pgs_iters=64)), ("mu 0.9, converged (64 sweeps)", dict(mu=0.9, pgs_iters=64)),
+                                       ("friction pyramid of rounds 1-2 (8 sweeps, mu 1.0)", dict(pyramid=1, mu=1.0)),
                                        ("friction pyramid, 16 sweeps", dict(pyramid=1, mu=1.0, pgs_iters=16)),
-                                       ("20 mm foot", dict(tip_radius=0.020)), ("1.5 N m torque clamp", dict(tau_max=1.5))])
+                                       ("20 mm foot", dict(tip_radius=0.020)), ("10 mm foot", dict(tip_radius=0.010)), ("1.5 N m torque clamp", dict(tau_max=1.5))])
 def test_negative_controls_fail_the_orientation_checks(robot_model, recordings, label, kw):
     """A broken simulator must not pass: each of these is rejected by the orientation / termination checks."""
     runs = run_all(robot_model, recordings, files=R.GOAL_KNOWN + ["test"], **kw)
     n = reached_by_kind(runs)
     print(label, n, "test ends on", runs["test"]["done_at"])
     assert not orientation_ok(runs), (label, n)
+
+
+@pytest.mark.parametrize("label, kw", [("drive damping 50", dict(kd=50.0)), ("drive damping 200", dict(kd=200.0)), ("drive limit 6 N m", dict(tau_max=6.0)),
+                                       ("drive limit 24 N m", dict(tau_max=24.0)), ("Baumgarte 0.5", dict(baumgarte=0.5))])
+def test_what_the_recordings_do_not_constrain(robot_model, recordings, label, kw):
+    """On record so that the replay test is not over-read: these variants pass every orientation / termination check (and the 5-of-7 episode
+    returns) - the recordings do not pin the drive's damping within 50 ... 200, any drive limit from 6 N m up, or the penetration push-out
+    fraction within 0.2 ... 0.5.  Those spec values rest on the reference's own numbers (kd 100: robot/quadruped_robot.py:61-64) or are this
+    engine's."""
+    runs = run_all(robot_model, recordings, files=R.GOAL_KNOWN + ["test"], **kw)
+    check_orientation(runs)
+    check_episode_reward(run_all(robot_model, recordings, files=R.GOAL_KNOWN, until_done=True, **kw))
+
+
+MU_GRID = (0.5, 0.6, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0, 1.1, 1.2)
+
+
+def mu_table(robot_model, recordings, sweeps):
+    """rows inside PhysX's success window per goal-known file, for every coefficient of the grid: {mu: [7 counts]}"""
+    return {mu: [r["in_window"] for r in run_all(robot_model, recordings, files=R.GOAL_KNOWN, mu=mu, pgs_iters=sweeps).values()] for mu in MU_GRID}
+
+
+def leave_one_out(tab):
+    """[(held-out file, coefficient with the most shared rows on the other six - first of the grid on ties -, held-out rows there)]"""
+    out = []
+    for k, name in enumerate(R.GOAL_KNOWN):
+        score = {mu: sum(v[j] for j in range(len(v)) if j != k) for mu, v in tab.items()}
+        best = max(MU_GRID, key=lambda m: score[m])
+        out.append((name, best, tab[best][k]))
+    return out
+
+
+def test_friction_coefficient_leave_one_out(robot_model, recordings):
+    """The coefficient 0.8 x nominal is FITTED on the seven goal-known episodes this file asserts (parity unpinned).  What the fit is
+    worth out of sample: chosen on any six episodes by the number of shared window rows it is 0.8 in >= 6 of 7 folds with the converged solve (the
+    seventh fold ties 0.6 / 0.75 / 0.8) and in 7 of 7 at the shipped 8 sweeps, and the held-out episode then shares >= 14 of its 17 rows in six folds
+    (the named `mlp_joint_loco_from_mani` shares none at any coefficient).  Chosen on the locomotion files alone it is the best coefficient for the
+    manipulation files and the other way round."""
+    for sweeps, folds in ((64, 6), (8, 7)):
+        tab = mu_table(robot_model, recordings, sweeps); loo = leave_one_out(tab)
+        print(sweeps, "sweeps:", loo)
+        assert sum(mu == 0.8 for _, mu, _ in loo) >= folds, loo
+        assert sum(rows >= 14 for _, _, rows in loo) >= 5 + (sweeps == 8), loo
+        if sweeps == 8:
+            loco = [i for i, n in enumerate(R.GOAL_KNOWN) if R.kind_of(n) == "loco"]; mani = [i for i, n in enumerate(R.GOAL_KNOWN) if R.kind_of(n) == "mani"]
+            for fit, held in ((loco, mani), (mani, loco)):
+                pick = max(MU_GRID, key=lambda m: sum(tab[m][i] for i in fit))
+                assert pick == 0.8, pick
+                assert sum(tab[pick][i] for i in held) == max(sum(tab[m][i] for i in held) for m in MU_GRID)
 
 
 def test_joint_level_checks_are_a_drive_limit_test(robot_model, recordings):
