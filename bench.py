@@ -14,9 +14,7 @@ the size of the rollout's returns + advantages -- over RCCL, inside the timed re
 Rank 0 also reports, outside the timed region: the same workload through the drop-in boundary itself (`VecEnvRLGames.step`,
 `config.vec_env_step_env_steps_per_s`: fresh output tensors and the extras dict per call, as the reference's wrapper hands them out),
 the zero-action protocol of SURVEY 8(d), the same envs with the reference's MLP policy in the loop (BASELINE config 2 names one):
-48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`), the headline workload under the OTHER reading of the drive
-limit (`config.torque_clamp_reading_env_steps_per_s`: max effort 1.5 as a 1.5 N m torque clamp; the default reads it as PhysX's per-step
-impulse limit - parity unpinned), BASELINE config 3 and config 4's per-GPU block (`config.manipulation_...`,
+48-step rollouts as one persistent kernel (`config.mlp_policy_in_loop_...`), BASELINE config 3 and config 4's per-GPU block (`config.manipulation_...`,
 `config.cotrain_block_...`), one PD-actuator task family (`config.pd_family_...`) and BASELINE config 5 (`config.config5_...`: vertical co-training, 8192 envs, GNN in the loop).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts `torch.distributed.run` with N ranks as a child BEFORE
@@ -264,7 +262,7 @@ def main():
             torch.cuda.synchronize(dev); mlp_rate = N * ROLLOUT * 20 / (time.perf_counter() - tr)
             ro.close()
         # other workloads of the path, same protocol (fresh U(-1,1) actions, 4096 envs), rank 0, untimed region: BASELINE config 3, config 4's
-        # per-GPU block, one PD-actuator family, and the headline under the torque-clamp reading of the drive limit
+        # per-GPU block, one PD-actuator family
         def rate_of(params, split=None, obs=64, steps=600):
             e2 = Engine(load_model("quadruped_robot_v2"), params, N, seed=42, device=str(dev), **({} if split is None else dict(split_env=split)))
             oo, ss = torch.empty(N, obs, device=dev), torch.empty(N, 93, device=dev)
@@ -279,7 +277,6 @@ def main():
             from locomanipulationrl_amd.engine_config import loco_cc_params, mani_params
             cq = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]
             extra_rates = {
-                "torque_clamp_reading_env_steps_per_s": rate_of([loco_params(drive_limits_are_impulses=False)]),
                 "manipulation_env_steps_per_s": rate_of([mani_params()]),
                 "cotrain_block_env_steps_per_s": rate_of([loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]),
                                                           mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], split=N // 2),
@@ -316,7 +313,9 @@ def main():
                        "vec_env_step_env_steps_per_s": vec_rate,
                        "zero_action_env_steps_per_s_rank0": zero_rate,
                        "mlp_policy_in_loop_env_steps_per_s_rank0": mlp_rate, **extra_rates,
-                       "drive_limit_reading": "max effort 1.5 read as an impulse limit (never binds on sustained loads; DESIGN.md 2.2: row 0 of the reference's recordings shows PhysX limiting the drive impulse per solver iteration); the 1.5 N m torque-clamp reading is timed beside it",
+                       "drive_limit_reading": "max effort 1.5 read as an impulse limit per step (never binds; DESIGN.md 2.1 / 2.2: the reference's recordings rule the 1.5 N m torque clamp out - it is the replay test's negative control; its bench leg and YAML switch were removed in round 4)",
+                       "all_gather_blocks_timed": len(ag_events),      # N > 1: the per-48-step all-gathers inside the timed region, rank 0
+                       "all_gather_ms_per_block_rank0": (sum(a.elapsed_time(b) for a, b in ag_events) / len(ag_events)) if ag_events else None,
                        "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step",

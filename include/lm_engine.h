@@ -44,7 +44,8 @@ extern "C" {
 /* Bumped whenever lm_params, the table layout or the meaning of an entry point changes.  Every lm_params block carries it together with the
  * caller's sizeof(lm_params) and LM_TABLE_FLOATS (first three fields); lm_create returns LM_EINVAL when any of them differs from what the
  * library was built with, instead of reading a shifted struct or past the end of a shorter table.
- *   1  round 1     2  round 2 (drive_mode, 502-float table; not stamped)     3  round 3 (the stamp itself; pgs_iters per contact surface) */
+ *   1  round 1     2  round 2 (drive_mode, 502-float table; not stamped)     3  round 3 (the stamp itself; pgs_iters per contact surface)
+ *   4  round 3 (pd_second_pass replaces sat_probe: the PD-actuator families decide their clamp on the pre-step state, one pass) */
 #define LM_ABI_VERSION 4
 
 /* Task / simulation constants for one task family.  Mirrors EngineParams (engine_config.py);
@@ -121,7 +122,11 @@ typedef struct lm_engine lm_engine;   /* opaque */
 /* Pointers the host side may wrap zero-copy.  LM_PTR_OBS_BUF, LM_PTR_STATES_BUF and LM_PTR_TERMS are the engine's own unclipped copies of
  * what lm_step's out_obs / out_states deliver clipped: lm_step keeps each of them current from the first lm_ptr() call for it on (ask before
  * the step whose values you want), and in any case when the matching out_* argument is NULL; a caller that only consumes the out_* buffers
- * does not pay for the second copy.  The staged entry points (lm_post_physics ...) always write them. */
+ * does not pay for the second copy.  The staged entry points (lm_post_physics ...) always write them.
+ * CAVEATS of the on-demand copies: (1) the first lm_ptr() call for one of the three changes what LATER lm_step launches write - the buffer it
+ * returns is zeros / an older step's values until the next step (the Python mirror warns when a view is first requested after stepping);
+ * (2) a hipGraph the CALLER captured around lm_step before that first lm_ptr() call keeps the kernel arguments of capture time (NULL view
+ * pointers) for ever: request the views you need before capturing.  lm_rollout's own graph is re-captured when the set of views changed. */
 typedef enum {
   LM_PTR_STATE = 0,     /* float [LM_STATE_ROWS][N]                                  */
   LM_PTR_CNT = 1,       /* int64 [LM_CNT_ROWS][N]: successes, consecutive_successes,

@@ -477,15 +477,25 @@ LM_DEV void integrate_free(FreeBody& F, const M3& R, float dt) {
 // Per-lane stash in LDS for the pass-invariant terms of a sub-step (they are needed at the top of each of the two
 // drive passes but not during the contact iterations; keeping them in registers across the PGS loop spills).
 // Layout [slot][lane] as float4 -> conflict-free 16-byte accesses.
+#ifdef LM_WAVES2
+// Diagnostic A/B build (tools/ab_build.py w2=-DLM_WAVES2): k_step compiled for TWO wavefronts per SIMD.  That needs
+// <= 256 registers per lane (amdgpu_waves_per_eu(2, 2): the compiler spills the rest to scratch) and <= 20 KB of LDS per wavefront (8 blocks per CU):
+// the stash shrinks to 18 slots (the limb's last two inertia entries ride in the free half of slot 4) and the output staging (sObs, sSt: dead until
+// the task layer, when the stash is dead) lives in the stash's memory.  Only k_step's velocity-drive specialisations are meaningful in this build.
+#define STASH_SLOTS 18
+#define LM_STEP_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
 #define STASH_SLOTS 22
+#define LM_STEP_ATTR
+#endif
 struct Stash {
   float4* base; int lane;
   LM_DEV void put(int slot, float a, float b, float c, float d) const { base[slot * 64 + lane] = make_float4(a, b, c, d); }
   LM_DEV float4 get(int slot) const { return base[slot * 64 + lane]; }
 };
-LM_DEV void stash_sv3(const Stash& S, int slot, SV a, SV b, SV c) {      // 18 floats -> 5 slots (last half used)
+LM_DEV void stash_sv3(const Stash& S, int slot, SV a, SV b, SV c, float e0 = 0.f, float e1 = 0.f) {      // 18 floats -> 5 slots (the last one half used: e0, e1 ride there)
   S.put(slot + 0, a.w.x, a.w.y, a.w.z, a.v.x); S.put(slot + 1, a.v.y, a.v.z, b.w.x, b.w.y);
-  S.put(slot + 2, b.w.z, b.v.x, b.v.y, b.v.z); S.put(slot + 3, c.w.x, c.w.y, c.w.z, c.v.x); S.put(slot + 4, c.v.y, c.v.z, 0.f, 0.f);
+  S.put(slot + 2, b.w.z, b.v.x, b.v.y, b.v.z); S.put(slot + 3, c.w.x, c.w.y, c.w.z, c.v.x); S.put(slot + 4, c.v.y, c.v.z, e0, e1);
 }
 LM_DEV void unstash_sv3(const Stash& S, int slot, SV& a, SV& b, SV& c) {
   float4 t0 = S.get(slot), t1 = S.get(slot + 1), t2 = S.get(slot + 2), t3 = S.get(slot + 3), t4 = S.get(slot + 4);
@@ -575,7 +585,11 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
     V3 e0 = K.s1.v + cross(K.s1.w, D.x);
     V3 e1 = D.j31.v + cross(D.j31.w, D.x);
     V3 e2 = D.j32.v + cross(D.j32.w, D.x);
+#ifdef LM_WAVES2
+    stash_sv3(St, 0, D.Fq0, D.Fq1, D.Fq2, D.Isc.xz, D.Isc.yz);
+#else
     stash_sv3(St, 0, D.Fq0, D.Fq1, D.Fq2);
+#endif
     St.put(5, D.H[0], D.H[1], D.H[2], D.H[3]); St.put(6, D.H[4], D.H[5], D.hq[0], D.hq[1]);
     // Jq = contact-coordinate tip velocity per unit joint rate: row 0 plain, rows 1 and 2 interleaved (Jq[1][c] | Jq[2][c])
     St.put(7, D.hq[2], dot(C0, e0), dot(C0, e1), dot(C0, e2));
@@ -586,7 +600,10 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       const V3 n0 = cross(D.x, C0), n1 = cross(D.x, C1), n2 = cross(D.x, C2);
       St.put(10, D.fcs.w.x, n0.x, D.fcs.w.y, n0.y); St.put(11, D.fcs.w.z, n0.z, D.fcs.v.x, C0.x); St.put(12, D.fcs.v.y, C0.y, D.fcs.v.z, C0.z);
       St.put(13, n1.x, n2.x, n1.y, n2.y); St.put(14, n1.z, n2.z, C1.x, C2.x); St.put(15, C1.y, C2.y, C1.z, C2.z);
-      St.put(16, D.Isc.m, D.Isc.h.x, D.Isc.h.y, D.Isc.h.z); St.put(17, D.Isc.xx, D.Isc.yy, D.Isc.zz, D.Isc.xy); St.put(18, D.Isc.xz, D.Isc.yz, 0.f, 0.f);
+      St.put(16, D.Isc.m, D.Isc.h.x, D.Isc.h.y, D.Isc.h.z); St.put(17, D.Isc.xx, D.Isc.yy, D.Isc.zz, D.Isc.xy);
+#ifndef LM_WAVES2
+      St.put(18, D.Isc.xz, D.Isc.yz, 0.f, 0.f);
+#endif
     }
   }
 
@@ -612,9 +629,10 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   float qdn[3]; SV un;
   for (int pass = 0; pass < 2; pass++) {
     asm volatile("" ::: "memory");          // keep the stash reloads inside the pass (no hoisting across the PGS loop)
-    S6 Fq0, Fq1, Fq2;
+    S6 Fq0, Fq1, Fq2; float isc_xz = 0.f, isc_yz = 0.f;
     {
       const float4 t0 = St.get(0), t1 = St.get(1), t2 = St.get(2), t3 = St.get(3), t4 = St.get(4);
+      isc_xz = t4.z; isc_yz = t4.w;
       Fq0.a = mk2(t0.x, t0.y); Fq0.b = mk2(t0.z, t0.w); Fq0.c = mk2(t1.x, t1.y);
       Fq1.a = mk2(t1.z, t1.w); Fq1.b = mk2(t2.x, t2.y); Fq1.c = mk2(t2.z, t2.w);
       Fq2.a = mk2(t3.x, t3.y); Fq2.b = mk2(t3.z, t3.w); Fq2.c = mk2(t4.x, t4.y);
@@ -647,7 +665,11 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
       PB[0].q = mk2(g3.x, g3.y); PB[1].q = mk2(g3.z, g3.w); PB[2].q = mk2(g4.x, g4.y); PB[3].q = mk2(g4.z, g4.w); PB[4].q = mk2(g5.x, g5.y); PB[5].q = mk2(g5.z, g5.w);
     }
     if (MODE == 0) {
-      const float4 g16 = St.get(16), g17 = St.get(17), g18 = St.get(18);
+#ifdef LM_WAVES2
+      const float4 g16 = St.get(16), g17 = St.get(17), g18 = make_float4(isc_xz, isc_yz, 0.f, 0.f);
+#else
+      const float4 g16 = St.get(16), g17 = St.get(17), g18 = St.get(18); (void)isc_xz; (void)isc_yz;
+#endif
       SI Isc; Isc.m = g16.x; Isc.h = v3(g16.y, g16.z, g16.w); Isc.xx = g17.x; Isc.yy = g17.y; Isc.zz = g17.z; Isc.xy = g17.w; Isc.xz = g18.x; Isc.yz = g18.y;
       // articulated hub inertia  A = sum over the quad of (Isc - K F^T): rows of pairs, upper triangle only
       float A0[6][6]; si_to_66(Isc, A0);
@@ -757,7 +779,9 @@ LM_DEV void substep(const lm_params* __restrict__ P, const float* th, const floa
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) {      // driven joints are speed-limited like PhysX's maxJointVelocity (config_module_joints.py:11,61-69)
-    if (VAR) tau_acc[a] += sat[a] ? tsat[a] : kd * (tgt[a] - qdn[a]);      // drive torque applied over this sub-step
+    // the LOGGED drive torque (observation 88, mechanical power): clipped like the reference's (…custom_controller.py:289-293); the implicit torque
+    // applied to an unsaturated joint can exceed the limit in 0.02 % of the joint-sub-steps when pd_second_pass = 0 - dynamics only, never logged
+    if (VAR) tau_acc[a] += sat[a] ? tsat[a] : fminf(fmaxf(kd * (tgt[a] - qdn[a]), -tmax[a]), tmax[a]);
     const float vm = DR ? X.vmax[a] : P->max_joint_vel;
     float v = fminf(fmaxf(qdn[a], -vm), vm);
     qd[a] = v; q[a] = fmaf(dt, v, q[a]);
@@ -1341,7 +1365,11 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
     }
   }
   DrOut DO; DO.drc = A.drc; DO.seed = A.seed; DO.dr_step = dr_step; DO.rand_buf = dr_rand_buf; DO.reset_key = dr_reset_key;
+#ifdef LM_WAVES2
+  DO.sKey = reinterpret_cast<uint32_t*>(sSt + ENVS_PER_WAVE * 93);      // behind the output staging, which lives in the stash's memory in this build
+#else
   DO.sKey = reinterpret_cast<uint32_t*>(sStash);      // the stash is dead after the last sub-step
+#endif
   LM_STAMP(8);      // state stores issued
   write_outputs<DR, DEFER, (VAR == 1) ? LM_MAX_OBS : 64>(P, A.W, N, env0, lane, limb, env, active, S, O, cnt, episode, sObs, sSt, DO);
   LM_STAMP(10);     // the reduction's round trips
@@ -1366,6 +1394,16 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
 #define LM_STEP_PROLOGUE
 #define LM_STEP_EPILOGUE
 #endif
+#ifdef LM_WAVES2
+#define LM_STEP_SMEM(NOBS) \
+  __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2]; \
+  __shared__ float4 sStash[STASH_SLOTS * 64]; \
+  static_assert(ENVS_PER_WAVE * ((NOBS) + 93 + 3) * 4 <= STASH_SLOTS * 64 * 16, "output staging must fit in the stash"); \
+  float* sObs = reinterpret_cast<float*>(sStash); float* sSt = sObs + ENVS_PER_WAVE * (NOBS); \
+  const int env0 = lm_block() * ENVS_PER_WAVE; \
+  const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0); \
+  const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
+#else
 #define LM_STEP_SMEM(NOBS) \
   __shared__ __attribute__((aligned(16))) float sTab[LM_ITAB_FLOATS + 2]; \
   __shared__ __attribute__((aligned(16))) float sObs[ENVS_PER_WAVE * (NOBS)]; \
@@ -1374,8 +1412,9 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   const int env0 = lm_block() * ENVS_PER_WAVE; \
   const lm_params* P = A.params + ((env0 >= A.split) ? 1 : 0); \
   const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
+#endif
 
-__global__ void __launch_bounds__(64) k_step(StepArgs A) {                 // velocity-drive tasks (kinds 0, 1)
+__global__ void __launch_bounds__(64) LM_STEP_ATTR k_step(StepArgs A) {                 // velocity-drive tasks (kinds 0, 1)
   LM_STEP_SMEM(64)
   LM_STEP_PROLOGUE
   if (kind == 0) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash);

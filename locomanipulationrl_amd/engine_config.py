@@ -22,8 +22,11 @@ trajectories (tests/golden/npy_traj.npz; tests/npy_replay
       never binding).  Whether the reference's Isaac build raised PxArticulationFlag::eDRIVE_LIMITS_ARE_FORCES cannot be checked here,
       and row 0 of the same recordings (the joints give way by 3e-3 ... 1.25e-2 rad while the scene settles) shows what the limit really is:
       an impulse limit of 1.5 N m x dt PER SOLVER ITERATION (16 per step), which binds only on loads that arrive inside one iteration - the
-      plate scene's start-in-penetration - and amounts to 24 N m on sustained ones (reproduced in a sub-iterated oracle run).  `drive_limits_are_impulses=False` selects
-      the torque reading; bench.py reports the headline under both.
+      plate scene's start-in-penetration - and amounts to 24 N m on sustained ones (reproduced in a sub-iterated oracle run; round 4
+      tried the drive as rows of the contact iteration with that per-iteration bound - 17 variants, none reproduces the recordings' later rows,
+      tests/drive_rows_experiment.py).  The torque reading (tau_max = 1.5 for the velocity drive) is the replay test's negative control; its YAML
+      switch `drive_limits_are_impulses` and bench leg were removed in round 4 (an unpinned reading at +36 % step time is not a feature):
+      `sim.engine.tau_max` sets an explicit limit for experiments.
   friction CONE, mu = 0.8 x the nominal coefficient, pgs_iters 8 (round 3): with the axis-aligned friction pyramid of rounds 1-2 the replay's
       orientation outcomes depended on the sweep count (1 of 4 locomotion files entered PhysX's success window at 8 sweeps, 3 of 4 from 12 on)
       and missed PhysX's rows by up to 6; with the isotropic cone |lam_t| <= mu lam_n they are THE SAME FROM 2 TO 128 SWEEPS and land on
@@ -36,7 +39,7 @@ trajectories (tests/golden/npy_traj.npz; tests/npy_replay
 from __future__ import annotations
 
 from dataclasses import dataclass, field, replace
-from typing import List
+from typing import Dict, List
 
 
 # Contact sweeps per solve, chosen on convergence (DESIGN.md 2.1, table `convergence` of tests/npy_replay_evidence.py): the smallest count of 4, 8,
@@ -83,12 +86,11 @@ class EngineParams:
     # ---- physics
     dt: float = 0.0083
     substeps: int = 4
-    pgs_iters: int = -1                 # contact sweeps per solve; -1 = by contact surface (PGS_ITERS_GROUND / _PLATE: 8 and 8, see above)
+    pgs_iters: int = -1                 # contact sweeps per solve; -1 = by contact surface / actuator (PGS_ITERS_GROUND / _PLATE / _PD: 8 / 4 / 4, see above)
     gravity: float = 9.81
     kd: float = 100.0
     max_effort: float = 1.5             # ArticulationView.set_max_efforts (robot.py:347-355); host-side only, tau_max is what the engine reads
-    drive_limits_are_impulses: bool = True
-    tau_max: float = -1.0               # -1 = from max_effort: max_effort / dt (impulse limit per step, see above) or max_effort (torque clamp)
+    tau_max: float = -1.0               # -1 = max_effort / dt: the velocity drive's limit read as an impulse limit per step (see above); the PD families set 1.5
     act_scale: float = 3.0
     mu: float = FRICTION_SCALE * 1.0     # effective friction coefficient of the foot contacts: FRICTION_SCALE x the nominal (combined) 1.0
     pyramid: int = 0                    # ORACLE-ONLY evidence switch: 1 = the axis-aligned friction pyramid of rounds 1-2 (the kernel implements the cone only)
@@ -178,14 +180,23 @@ class EngineParams:
     tgs_flags: int = 0
     # ---- bookkeeping
     max_reset_counts: int = 2048        # success-rate window (quadruped_pose_control.py:151)
+    # values the -1 sentinels above were resolved to ({field: value}).  dataclasses.replace() hands every field back to __init__, the resolved ones
+    # included: a field that still holds the value recorded here was not set by the caller and is derived again from the (possibly replaced) dt,
+    # max_effort, mode and variant - replace(loco_params(), dt=0.005).tau_max is 300, not 180.7
+    derived: Dict[str, float] = field(default_factory=dict, repr=False, compare=False)
 
     def __post_init__(self):
-        if self.tau_max < 0:
-            self.tau_max = self.max_effort / self.dt if (self.drive_limits_are_impulses and self.dt > 0) else self.max_effort
-        if self.drive_iter_impulse < 0:
-            self.drive_iter_impulse = self.max_effort * self.dt
-        if self.pgs_iters < 0:
-            self.pgs_iters = PGS_ITERS_PD if self.variant != 0 else PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE
+        auto = dict(self.derived)
+
+        def resolve(name, value):
+            if getattr(self, name) < 0 or (name in auto and getattr(self, name) == auto[name]):
+                setattr(self, name, value); auto[name] = value
+            else:
+                auto.pop(name, None)
+        resolve("tau_max", self.max_effort / self.dt if self.dt > 0 else self.max_effort)
+        resolve("drive_iter_impulse", self.max_effort * self.dt)
+        resolve("pgs_iters", PGS_ITERS_PD if self.variant != 0 else PGS_ITERS_GROUND if self.mode == MODE_LOCO else PGS_ITERS_PLATE)
+        self.derived = auto
 
     @property
     def ctrl_dt(self) -> float:

@@ -222,6 +222,7 @@ class Engine:
         self.cnt = self._wrap(PTR_CNT, (CNT_ROWS, N), "<i8")
         self.num_obs = int(self.lib.lm_num_obs(self._h))
         self._views = {}            # obs_buf / states_buf / terms: asked for on first access (lm_step writes them only from then on)
+        self._steps_run = 0         # lm_step calls so far (a first view request after stepping is stale: warned about)
         self.rew_buf = self._wrap(PTR_REW_BUF, (N,), "<f4")
         self.extras_buf = self._wrap(PTR_EXTRAS, (NUM_EXTRAS,), "<f4")
         self.stats_i64 = self._wrap(PTR_STATS, (6,), "<i8")
@@ -231,6 +232,11 @@ class Engine:
 
     def _view(self, kind, shape):
         if kind not in self._views:
+            if self._steps_run:
+                # lm_step starts writing this buffer with the NEXT step: what it holds now is zeros or an older step's values
+                import warnings
+                warnings.warn("lm_engine: an unclipped view (obs_buf / states_buf / terms) was first requested after %d step(s): it is stale until the next "
+                              "step (ask for it before stepping; include/lm_engine.h, lm_ptr_kind)" % self._steps_run, RuntimeWarning, stacklevel=3)
             self._views[kind] = self._wrap(kind, shape, "<f4")
         return self._views[kind]
 
@@ -291,6 +297,7 @@ class Engine:
             assert out_resets.dtype == self.torch.int64 and tuple(out_resets.shape) == (N,) and out_resets.device == self.device and out_resets.is_contiguous()
         self._check(self.lib.lm_step(self._h, self._p(actions), self._p(goal_rand), self._p(out_obs), self._p(out_states),
                                      self._p(out_rew), self._p(out_resets), self._p(out_extras), self._stream()))
+        self._steps_run += 1
 
     def post_physics(self, actions, out_obs=None, out_states=None, out_rew=None, out_resets=None, out_extras=None):
         self._f32(actions, (self.num_envs, NUM_ACTIONS))

@@ -402,7 +402,11 @@ static void substep_one(const lmo_model* m, const lmo_params* p, real* phys, con
       int any=0; for (int j=0;j<12;j++) { if (sat[j]) continue; real tau=kd*(target[j]-un[6+j]); real tm=g_dr?g_dr->tmax[j]:tmax; if (tau>tm){sat[j]=1;tsat[j]=tm;any=1;} else if (tau<-tm){sat[j]=1;tsat[j]=-tm;any=1;} }
       if (!any) break; }
   }
-  if (tau_out) for (int j=0;j<12;j++) tau_out[j] = sat[j] ? tsat[j] : kd*(target[j]-un[6+j]);   /* drive torque applied over this sub-step */
+  /* the drive torque LOGGED for this sub-step (observation 88 and the mechanical-power term of the PD-actuator tasks): the reference clips the torque
+     before applying and logging it (quadruped_pose_control_custom_controller.py:289-293), so the log never leaves +-max_effort.  With pd_second_pass = 0
+     the implicit torque APPLIED to an unsaturated joint, kd (v* - qd_end), can exceed the limit (0.02 % of the joint-sub-steps, by at most kd x the
+     sub-step's velocity change): that excess is dynamics-only, the logged value is clipped */
+  if (tau_out) for (int j=0;j<12;j++) { real tm=g_dr?g_dr->tmax[j]:tmax, t = sat[j] ? tsat[j] : kd*(target[j]-un[6+j]); tau_out[j] = t>tm?tm:(t<-tm?-tm:t); }
   /* integrate; driven joints are speed-limited like PhysX's maxJointVelocity (Design/Scripts/config_module_joints.py:11,61-69) */
   for (int j=0;j<12;j++) { real v=un[6+j]; real vm=g_dr?g_dr->vmax[j]:(real)p->max_joint_vel; if (v>vm) v=vm; if (v<-vm) v=-vm; phys[25+j]=v; phys[13+j]+=dt*v; }
   {

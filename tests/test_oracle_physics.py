@@ -117,7 +117,7 @@ def test_reference_npy_row0_envelope(robot_model):
 def test_saturated_drive_respects_torque_limit(robot_model):
     """A target far from the joint velocity saturates the drive: the velocity change per sub-step is bounded by
     tau_max * dt / (smallest joint-space inertia), not by the 100 N m s/rad gain."""
-    ep = loco_params(tau_max=1.5); o = Oracle(robot_model, ep)      # a real 1.5 N m clamp (the PD-actuator families; `drive_limits_are_impulses: False`)
+    ep = loco_params(tau_max=1.5); o = Oracle(robot_model, ep)      # a real 1.5 N m clamp (the PD-actuator families; `sim.engine.tau_max: 1.5`)
     phys, task, cnt = o.new_state(1); o.reset(phys, task, cnt); phys[0, 2] = 5.0
     M, _ = o.dyn_terms(phys[0])
     o.substep(phys, np.full((1, 12), 3.0))
@@ -151,7 +151,10 @@ def test_pd_actuator_clamp_follows_the_reference_rule(robot_model):
                 tg = ep.pd_kp / ep.kd * (qstar - phys[:, 13:25]); tau_e = ep.kd * (tg - phys[:, 25:37])
                 tau = o.substep_tau(phys, tg); S = np.abs(tau_e) > ep.tau_max
                 assert np.allclose(tau[S], np.sign(tau_e[S]) * ep.tau_max)
-                n += S.size; n_sat += int(S.sum()); n_over += int((np.abs(tau) > ep.tau_max * (1 + 1e-9)).sum()); worst = max(worst, float(np.abs(tau).max()))
+                assert (np.abs(tau) <= ep.tau_max * (1 + 1e-12)).all()            # the LOGGED torque is clipped like the reference's (:289-293), whatever was applied
+                on_limit = np.abs(tau) >= ep.tau_max * (1 - 1e-12)                # joints the solve put on the limit (pre-step rule, or the second pass)
+                applied = np.where(on_limit & (S | bool(second)), tau, ep.kd * (tg - phys[:, 25:37]))      # the others: the implicit torque on the end-of-step velocity
+                n += S.size; n_sat += int(S.sum()); n_over += int((np.abs(applied) > ep.tau_max * (1 + 1e-9)).sum()); worst = max(worst, float(np.abs(applied).max()))
         assert n_sat > 0.01 * n, n_sat / n
         if second:
             assert n_over <= 1e-4 * n, n_over / n

@@ -1,4 +1,6 @@
-"""Throughput of lm_step versus environment count and task family (documentation numbers, not the headline bench)."""
+"""Throughput of lm_step versus environment count and task family (documentation numbers, not the headline bench).
+    python tools/bench_sweep.py                      the full table (env counts on the locomotion task, then the other task families at 4096)
+    python tools/bench_sweep.py 16384,32768,65536    the locomotion task at these env counts only (A/B builds: LM_ENGINE_SO=tools/diag/liblm_engine_<name>.so)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,10 +22,14 @@ def run(task_name, N, steps=300, warmup=50):
     for t in range(steps): eng.step(pool[t % 16], None, *o)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     eng.close()
-    return {"task": task_name, "envs": N, "us_per_step": dt * 1e6, "M_env_steps_per_s": N / dt / 1e6}
+    return {"task": task_name, "envs": N, "us_per_step": dt * 1e6, "M_env_steps_per_s": N / dt / 1e6, "library": os.path.basename(os.environ.get("LM_ENGINE_SO", "product"))}
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for N in (int(x) for x in sys.argv[1].split(",")):
+            print(json.dumps(run(sys.argv[2] if len(sys.argv) > 2 else "QuadrupedPoseControl", N)), flush=True)
+        sys.exit(0)
     for N in (1024, 4096, 8192, 16384, 32768, 65536, 131072):
         print(json.dumps(run("QuadrupedPoseControl", N)), flush=True)
     for tn in ("QuadrupedManipulatePlate", "JointLocomanipulation", "QuadrupedPoseControlVertical", "JointLocomanipulationVertical"):
