@@ -37,7 +37,7 @@ BYTES_PER_ENV_STEP = 1488          # algorithmic HBM bytes per env-step (SURVEY 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE / flop counters, tools/profile_round.sh): counters cannot be
 # collected from inside the run, so `roofline.traffic` and `valu.flop_per_env_step` are READ FROM the newest of these files and labelled so
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")]
 
 
 def _omp_threads(n):

@@ -14,6 +14,7 @@ the reference's torch code.
 """
 from __future__ import annotations
 
+import sys
 from typing import List, Optional
 
 from ..engine_config import FRICTION_SCALE, MODE_LOCO, MODE_MANI, EngineParams
@@ -87,7 +88,7 @@ class _QuadrupedTask(RLTask):
             # said once per process, next to the YAML's own number: the friction materials of the task YAMLs do NOT mean what they say in this engine
             _QuadrupedTask._friction_scale_logged = True
             print(f"[locomanipulationrl_amd] foot friction: nominal (YAML, combined) {mu:.3g} x sim.engine.friction_scale {scale:.3g} = {mu * scale:.3g} "
-                  f"(fitted on the reference's PhysX recordings, parity unpinned; set sim.engine.friction_scale: 1.0 for the YAML value)")
+                  f"(fitted on the reference's PhysX recordings, parity unpinned; set sim.engine.friction_scale: 1.0 for the YAML value)", file=sys.stderr)
         mu *= scale
         rd = robot.robot_description
         if rd.control_mode not in ("velocity", "position", "effort"):          # robot.py:323-333

@@ -271,3 +271,47 @@ def test_persistent_rollout_kernel_equals_graph_replay(task_name, N, policy):
     assert int(ros[0].dones.sum()) > 0                        # episodes did end inside the window
     for r in ros: r.close()
     for e in engs: e.close()
+
+
+def _plain_graph_layer(layer, h, edge_index):
+    """GraphLayer restated without scatter_reduce: per target node, the messages of its incoming edges are stacked and reduced by torch.max(dim) -
+    a different autograd path (index-select backward of the max instead of amax's mask backward) through the same arithmetic."""
+    src, tgt = edge_index[0].tolist(), edge_index[1].tolist()
+    out = []
+    for i in range(h.shape[-2]):
+        inc = [e for e in range(len(tgt)) if tgt[e] == i]
+        m = torch.stack([layer.elu2(layer.linear2(layer.elu1(layer.linear1(torch.cat([h[..., tgt[e], :], h[..., src[e], :]], -1))))) for e in inc], -2)
+        out.append(m.max(dim=-2).values)
+    return torch.stack(out, -2)
+
+
+def test_gnn_backward_is_the_plain_per_node_backward():
+    """the GNN forward is pinned to the reference's outputs, its BACKWARD (what PPO trains through: scatter_reduce 'amax')
+    was not.  In float64: (1) finite differences agree with autograd on GraphLayer and on the whole GraphPolicy (gradcheck); (2) the gradients of
+    every parameter and of the input agree to 1e-12 with a plain per-node restatement that reduces with torch.max over stacked messages - no
+    scatter, another backward formula; (3) at an exact tie amax splits the gradient evenly where max(dim) picks one index (the sums agree): a
+    measure-zero case for continuous observations.  So the learner's gradient path is the textbook one; the GNN's slow PPO curve (DESIGN.md 6.1:
+    not reproduced) is not a backward bug."""
+    from locomanipulationrl_amd.policies.graph_model import GraphLayer, GraphPolicy, create_edge_index
+    torch.manual_seed(0)
+    ei = create_edge_index()
+    layer = GraphLayer(8, 8, 8).double()
+    h = torch.randn(3, 13, 8, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda x: layer(x, ei), (h,), eps=1e-6, atol=1e-7)
+    a = layer(h, ei); b = _plain_graph_layer(layer, h, ei)
+    assert float((a - b).abs().max()) < 1e-14          # (batched against per-edge matmuls: summation order only)
+    w = torch.randn_like(a)
+    ga = torch.autograd.grad((a * w).sum(), [h] + list(layer.parameters()))
+    gb = torch.autograd.grad((b * w).sum(), [h] + list(layer.parameters()))
+    assert max(float((x - y).abs().max()) for x, y in zip(ga, gb)) < 1e-12
+    # the whole policy: mean and value heads through three layers (64-wide observation, batch 2)
+    pol = GraphPolicy().double()
+    obs = torch.randn(2, 64, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda o: torch.cat([pol(o)[0], pol(o)[2]], -1), (obs,), eps=1e-6, atol=1e-6)
+    # an exact tie: two incoming messages of node 5 made identical (sources 1 and 9 carry the same features)
+    ht = torch.randn(1, 13, 8, dtype=torch.float64); ht[0, 9] = ht[0, 1]; ht.requires_grad_(True)
+    ta = layer(ht, ei); tb = _plain_graph_layer(layer, ht, ei)
+    assert float((ta - tb).abs().max()) < 1e-14
+    g1, = torch.autograd.grad(ta[0, 5].sum(), ht, retain_graph=True); g2, = torch.autograd.grad(tb[0, 5].sum(), ht)
+    assert float((g1[0, 1] + g1[0, 9] - g2[0, 1] - g2[0, 9]).abs().max()) < 1e-12          # same total; amax halves it between the tied sources
+    assert float((g1[0, 1] - g1[0, 9]).abs().max()) < 1e-12

@@ -63,7 +63,7 @@ class Geometry:
         return R, p
 
     def flags(self, state, ep, sl):
-        """(frame, hull, axis) boolean vectors over the envs of slice `sl` (a manipulation block with parameters `ep`)."""
+        """(frame, hull, axis, hull-at-the-rim) boolean vectors over the envs of slice `sl` (a manipulation block with parameters `ep`)."""
         s = state[:, sl].T
         N = s.shape[0]
         Rb = quat_to_mat(torch.tensor(ep.fixed_base_quat, device=self.dev).expand(N, 4)); pb = torch.tensor(ep.fixed_base_pos, device=self.dev).expand(N, 3)
@@ -86,7 +86,10 @@ class Geometry:
         tt = torch.linspace(0, 1, 11, device=self.dev)
         pts = torch.cat([(a[:, None, :] + (tt * f)[None, :, None] * (b_ - a)[:, None, :]) for a, b_, f in segs], 1)      # (N, 16 x 11, 3)
         y = to_plate(pts)
-        return frame, in_slab(y, HULL_R).any(1), in_slab(y, 0.0).any(1)
+        hit = in_slab(y, HULL_R)
+        # where a hull overlap sits: within 10 mm of the plate's rim (a foot has slipped off the edge and the link crosses the rim) or over the face
+        rim = (hit & ((y[..., 0].abs() > 0.24) | (y[..., 1].abs() > 0.24))).any(1)
+        return frame, hit.any(1), in_slab(y, 0.0).any(1), rim
 
 
 def mani_blocks(task):
@@ -97,18 +100,18 @@ def mani_blocks(task):
 
 
 def count(env, geo, actions_fn, steps):
-    task = env._task; blocks = mani_blocks(task); tot = dict(env_steps=0, frame=0, hull=0, axis=0, any=0, resets=0, frame_live=0, hull_live=0, any_live=0)
+    task = env._task; blocks = mani_blocks(task); tot = dict(env_steps=0, frame=0, hull=0, axis=0, any=0, resets=0, frame_live=0, hull_live=0, any_live=0, hull_live_at_rim=0)
     obs = env.reset()["obs"]
     for t in range(steps):
         o, rew, done, _ = env.step(actions_fn(obs)); obs = o["obs"]
         st = task.engine.state
         for ep, sl in blocks:
-            f, hl, ax = geo.flags(st, ep, sl)
+            f, hl, ax, rim = geo.flags(st, ep, sl)
             tot["env_steps"] += int(f.numel()); tot["frame"] += int(f.sum()); tot["hull"] += int(hl.sum()); tot["axis"] += int(ax.sum()); tot["any"] += int((f | hl).sum())
             tot["resets"] += int(done[sl].sum())
             live = done[sl] == 0          # the step did not end the episode: an intersection here is one the task's own tests have NOT caught
-            tot["frame_live"] += int((f & live).sum()); tot["hull_live"] += int((hl & live).sum()); tot["any_live"] += int(((f | hl) & live).sum())
-    for k in ("frame", "hull", "axis", "any", "frame_live", "hull_live", "any_live"):
+            tot["frame_live"] += int((f & live).sum()); tot["hull_live"] += int((hl & live).sum()); tot["any_live"] += int(((f | hl) & live).sum()); tot["hull_live_at_rim"] += int((rim & live).sum())
+    for k in ("frame", "hull", "axis", "any", "frame_live", "hull_live", "any_live", "hull_live_at_rim"):
         tot[k + "_pct"] = round(100.0 * tot[k] / max(tot["env_steps"], 1), 4)
     return tot
 
