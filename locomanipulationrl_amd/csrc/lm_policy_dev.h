@@ -7,6 +7,62 @@
 #include "lm_rng.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// ---- fp32 matrix products on the fp16 matrix pipe (GNN tile, round 4).  v_mfma_f32_16x16x32_f16 contracts K = 32 in ONE instruction of 16
+// cycles where v_mfma_f32_16x16x4_f32 needs 8 instructions of 32 (and reaches 46-48 with fresh operands): 16 x the rate.  Every fp32
+// operand is split into two halves, x = hi + lo with hi = fp16(x) and lo = fp16(x - hi) (both round-to-nearest; x - hi is exact in fp32), which
+// carries 22 bits of x (|x - hi - lo| <= 2^-23 |x|: the size of an fp32 rounding), and a product is the four MFMAs lo.lo + lo.hi + hi.lo + hi.hi
+// accumulated in fp32, smallest terms first.  fp16 range: |x| < 65504 (observations are clipped to +-5 by the scaler, activations of the 32-wide
+// layers stay orders of magnitude below); a lo below the fp16 subnormals (|x| < 6e-5 or so) loses bits that are < 6e-8 absolute.
+// 12 vector instructions per 8 values: v_cvt_pk_f16_f32 for a pair of hi halves, then lo = fp16(x - hi) as ONE mixed-precision FMA per value
+// (v_fma_mixlo / mixhi_f16: fp16 source hi, fp32 source x, fp32 arithmetic, result rounded once to fp16 into the low / high half) - written as
+// plain conversions the compiler emits 20 (two packed converts, four unpacking converts and a packed subtract per pair).
+// HAZARD (gfx940+ "dst-sel forwarding"): a VALU instruction that writes HALF of a register must not be followed directly by an instruction
+// that consumes that register - and v_fma_mixhi_f16 consumes its own destination (it preserves the low half).  The hazard recogniser does
+// not look inside inline assembly (a first version with mixlo directly followed by mixhi on the same register returned stale halves,
+// depending on timing), so the eight instructions are ordered by hand - four mixlo, then four mixhi: every mixhi is four instructions behind
+// its mixlo - and the block ends with one wait state before the compiler's consumers.
+__device__ __forceinline__ void split_f16(const float (&x)[8], f16x8& hi, f16x8& lo) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 H, L;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const f32x2 v = {x[2 * i], x[2 * i + 1]};
+    H[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));            // v_cvt_pk_f16_f32 (round to nearest even)
+  }
+#ifdef LM_GNN_NOASM
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const f32x2 v = {x[2 * i], x[2 * i + 1]};
+    const f32x2 r = v - __builtin_convertvector(__builtin_bit_cast(f16x2, H[i]), f32x2);
+    L[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  }
+#else
+  uint32_t l0, l1, l2, l3;
+  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0"
+      : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(H[0]), "v"(H[1]), "v"(H[2]), "v"(H[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  L[0] = l0; L[1] = l1; L[2] = l2; L[3] = l3;
+#endif
+  hi = __builtin_bit_cast(f16x8, H); lo = __builtin_bit_cast(f16x8, L);
+}
+__device__ __forceinline__ f32x4 mfma_split(const f16x8& ahi, const f16x8& alo, const f16x8& bhi, const f16x8& blo, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, blo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
+}
 
 // Block barrier for data exchanged through LDS only: waits for this wavefront's LDS operations, not for its global loads and stores
 // (__syncthreads() also drains vmcnt, which would stall every barrier on the weight prefetch that is deliberately kept in flight across it).
@@ -21,6 +77,15 @@ __device__ __forceinline__ void lds_barrier() {
 // No compare / select: e^x - 1 >= x everywhere, so ELU(x) is the median of (x, 0, e^x - 1) - x < e^x - 1 < 0 below zero, 0 < x < e^x - 1 above
 // (v_med3_f32; one instruction less per activation, and the activations are the VALU work that competes with the MFMAs of the policy tiles).
 __device__ __forceinline__ float elu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __expf(x) - 1.0f); }
+// two activations at once, ELU(p + q): the add, the scaling of the exponent and the -1 are packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32),
+// 7 vector instructions per pair instead of 10
+typedef __attribute__((ext_vector_type(2))) float elu_f32x2;
+__device__ __forceinline__ void elu_sum2(float p0, float p1, float q0, float q1, float& z0, float& z1) {
+  const elu_f32x2 x = (elu_f32x2){p0, p1} + (elu_f32x2){q0, q1};
+  const elu_f32x2 t = x * (elu_f32x2){1.4426950408889634f, 1.4426950408889634f};
+  const elu_f32x2 e = (elu_f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} - (elu_f32x2){1.0f, 1.0f};
+  z0 = __builtin_amdgcn_fmed3f(x.x, 0.0f, e.x); z1 = __builtin_amdgcn_fmed3f(x.y, 0.0f, e.y);
+}
 
 
 #ifdef LM_GNN_STAMPS
@@ -497,19 +562,22 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
   // critical path with a barrier between the stages.  Weights are loaded a stage ahead (they do not depend on activations).
   GNN_STAMP(1);      // input layers
   f32x4 P[NC][2];
+  // k-slot e (0..7) of lane group g of the 16x16x32 operands = feature 16 (e >> 2) + 4 g + (e & 3): the accumulator's own feature order, for
+  // the weights (gathered so by load_stage1 / the W2 loads) and for the activations alike - h, P and z still never leave the registers
   auto stage1 = [&](int layer) {
     float* sQ = sPQ + (layer & 1) * GNN_Q_BUF;
+    f16x8 wah[4], wal[4];
+#pragma unroll
+    for (int ob4 = 0; ob4 < 4; ob4++) split_f16(wa[ob4], wah[ob4], wal[ob4]);
 #pragma unroll
     for (int j = 0; j < NC; j++) {
       f32x4 acc[4];
+      float hb[8];
 #pragma unroll
-      for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int st = 0; st < 8; st++) hb[st] = h[j][st >> 2][st & 3];
+      f16x8 bh, bl; split_f16(hb, bh, bl);
 #pragma unroll
-      for (int st = 0; st < 8; st++) {
-        const float bb = h[j][st >> 2][st & 3];
-#pragma unroll
-        for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ob4][st], bb, acc[ob4], 0, 0, 0);
-      }
+      for (int ob4 = 0; ob4 < 4; ob4++) acc[ob4] = mfma_split(wah[ob4], wal[ob4], bh, bl, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int mb = 0; mb < 2; mb++) {
 #pragma unroll
@@ -546,6 +614,8 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
       // max_e ELU(y_e + b) = ELU(max_e y_e + b): ELU and the bias add are monotonic, so the activation is applied once per target node.
       const float* sQ = sPQ + (layer & 1) * GNN_Q_BUF;
       constexpr int NE = gnn_ne(WAVE);
+      f16x8 wbh[2], wbl[2];
+      split_f16(wb[0], wbh[0], wbl[0]); split_f16(wb[1], wbh[1], wbl[1]);
       f32x4 acc[2][2], mx[NC][2];
 #pragma unroll
       for (int j = 0; j < NC; j++) mx[j][0] = mx[j][1] = (f32x4){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
@@ -567,20 +637,24 @@ __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B
       {
         f32x4 q0, q1; q_of(0, q0, q1);
 #pragma unroll
-        for (int st = 0; st < 8; st++) zc[st] = elu(P[gnn_ej(WAVE, 0)][st >> 2][st & 3] + ((st >> 2) ? q1[st & 3] : q0[st & 3]));
+        for (int st = 0; st < 8; st += 2) { const f32x4& pp = P[gnn_ej(WAVE, 0)][st >> 2]; const f32x4& qq = (st >> 2) ? q1 : q0;
+          elu_sum2(pp[st & 3], pp[(st & 3) + 1], qq[st & 3], qq[(st & 3) + 1], zc[st], zc[st + 1]); }
       }
 #pragma unroll
       for (int e = 0; e < NE; e++) {
         f32x4 q0, q1; float zn[8];
         if (e + 1 < NE) q_of(e + 1, q0, q1);
-        acc[e & 1][0] = acc[e & 1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f16x8 zh, zl; split_f16(zc, zh, zl);
+        // the 8 MFMAs of edge e (two output blocks x four half products) issue while the activations of edge e+1 and the aggregation of edge
+        // e-1 run on the vector ALU (an MFMA holds the issue port for 8 of its 16 cycles)
+        acc[e & 1][0] = mfma_split(wbh[0], wbl[0], zh, zl, (f32x4){0.f, 0.f, 0.f, 0.f});
+        acc[e & 1][1] = mfma_split(wbh[1], wbl[1], zh, zl, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if (e + 1 < NE) {
 #pragma unroll
-        for (int st = 0; st < 8; st++) {
-          acc[e & 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][st], zc[st], acc[e & 1][0], 0, 0, 0);
-          acc[e & 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][st], zc[st], acc[e & 1][1], 0, 0, 0);
-          if (e + 1 < NE) zn[st] = elu(P[gnn_ej(WAVE, e + 1)][st >> 2][st & 3] + ((st >> 2) ? q1[st & 3] : q0[st & 3]));
-          if (e >= 1 && st == 3) aggregate(e - 1);
+          for (int st = 0; st < 8; st += 2) { const f32x4& pp = P[gnn_ej(WAVE, e + 1)][st >> 2]; const f32x4& qq = (st >> 2) ? q1 : q0;
+            elu_sum2(pp[st & 3], pp[(st & 3) + 1], qq[st & 3], qq[(st & 3) + 1], zn[st], zn[st + 1]); }
         }
+        if (e >= 1) aggregate(e - 1);
         if (e + 1 < NE) {
 #pragma unroll
           for (int st = 0; st < 8; st++) zc[st] = zn[st];
