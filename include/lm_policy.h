@@ -27,12 +27,15 @@ int lm_gnn_forward(const float* obs, int batch, const float* params, float* mean
 /* MLP policy of the locomotion / manipulation scripts (scripts/skrl_ppo_locomotion.py:30-40: shared trunk
  * Linear(64,256) ELU Linear(256,128) ELU Linear(128,64) ELU, mean_layer Linear(64,12), value_layer Linear(64,1)) with the
  * observation preprocessor (skrl RunningStandardScaler, :96-99) folded in.  `params` is the block produced by
- * locomanipulationrl_amd.policies.mlp_model.pack_mlp_params (weights pre-permuted into MFMA operand order);
- * lm_mlp_param_count() is its length.  Outputs as lm_gnn_forward (mean in the env's action order). */
+ * locomanipulationrl_amd.policies.mlp_model.pack_mlp_params: biases and the scaler as floats; every weight matrix as 32-bit words
+ * [out/16][K-blocks of 32][64 lanes][8] in the operand order of v_mfma_f32_16x16x32_f16, each weight split into two fp16 halves
+ * (w = hi + lo; words 0..3 the hi halves, 4..7 the lo halves) - the tile computes fp32 products as four half products, fp32-level accuracy
+ * (layout and column map: csrc/lm_policy_dev.h; round 4 - rounds 1-3 packed plain floats in v_mfma_f32_16x16x4_f32 order, same word counts for
+ * num_obs 64).  lm_mlp_param_count() is its length.  Outputs as lm_gnn_forward (mean in the env's action order). */
 int lm_mlp_param_count(void);
 int lm_mlp_forward(const float* obs, int batch, const float* params, float* mean, float* value, void* stream);
 /* The same network on the 88-wide observation of the custom-controller tasks (…custom_controller.py:432-455) or the 64-wide one:
- * num_obs in {64, 88}; the packed block is  mean num_obs | 1/std num_obs | clip (+3 pad) | W1p 256 x num_obs | ... as above. */
+ * num_obs in {64, 88}; the packed block is  mean num_obs | 1/std num_obs | clip (+3 pad) | W1q 256 x (num_obs padded to a multiple of 32) | ... as above. */
 int lm_mlp_param_count_obs(int num_obs);
 int lm_mlp_forward_obs(const float* obs, int batch, int num_obs, const float* params, float* mean, float* value, void* stream);
 

@@ -7,10 +7,12 @@
 //   obs (B,64)  ->  action means (B,12) in node order [dof1 a1..a4, dof2 a1..a4, dof3 a1..a4], value (B,1).
 //
 // Mapping: one block = 16 samples on the four wavefronts of a CU (node ownership, see gnn_body).  Every dense product runs as  D(features x samples) = W(features x K) * X(K x samples)
-// on v_mfma_f32_16x16x4_f32 (exact fp32, = an fmaf chain), weights as the A operand, activations as the B operand, so an
-// accumulator tile (feature rows in the 4 registers / 4 lane groups, sample on the lane) feeds the next product's B operand
-// with no lane movement: only the k order inside the dot product is permuted, and the A operand is gathered in the same
-// permuted order.  W1 [h_i || h_j] is split into per-node products P = W1a h + b1 (as target) and Q = W1b h (as source),
+// with the weights as the A operand and the activations as the B operand, so an accumulator tile (feature rows in the 4 registers / 4 lane
+// groups, sample on the lane) feeds the next product's B operand with no lane movement: only the k order inside the dot product is
+// permuted, and the A operand is gathered in the same permuted order.  Rounds 1-3 ran the 32-wide products on v_mfma_f32_16x16x4_f32 (8
+// instructions each); since round 4 they run on v_mfma_f32_16x16x32_f16 (ONE instruction per K = 32) with every fp32 operand split into two fp16
+// halves and the four half products accumulated in fp32 (lm_policy_dev.h split_f16 / mfma_split: fp32-level accuracy, 16 x the matrix rate);
+// the two small input layers (K = 16 and K = 4) stay on the fp32 instruction.  W1 [h_i || h_j] is split into per-node products P = W1a h + b1 (as target) and Q = W1b h (as source),
 // staged once per layer in LDS, so the 24 edge messages need only the 32x32 second linear layer:
 //   m_e = ELU(W2 ELU(P[tgt] + Q[src]) + b2),  h'[tgt] = max_e m_e.
 #include <hip/hip_runtime.h>

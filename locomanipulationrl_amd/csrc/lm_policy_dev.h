@@ -116,17 +116,26 @@ struct SampleArgs { const float* log_std; const int64_t* cnt; uint32_t seed; flo
 // ------------------------------------------------------------------------------------------------
 // MLP policy (scripts/skrl_ppo_locomotion.py:30-40): shared trunk 64 -> 256 -> 128 -> 64 (ELU) -> mean (12) + value (1),
 // with the observation preprocessor folded in (skrl RunningStandardScaler: clamp((x - mean) / (sqrt(var) + eps), +-clip),
-// passed as mean / inverse-std vectors).  Same orientation as the GNN: weights are the MFMA A operand, pre-permuted on the
-// host into the per-lane order each v_mfma_f32_16x16x4_f32 consumes (one coalesced 256-byte load per MFMA), activations stay
-// in accumulator layout from layer to layer.
-//   packed block: obs_mean 64 | obs_inv_std 64 | clip 1 (+3 pad) | W1p 256x64 | b1 256 | W2p 128x256 | b2 128 | W3p 64x128 | b3 64 |
-//                 Whp 16x64 (rows 0..11 mean, 12 value, 13..15 zero) | bh 16
-// offsets as functions of the observation width NOBS (64: velocity-drive / position-control tasks, 88: custom-controller tasks)
+// passed as mean / inverse-std vectors).
+//
+// Round 4: fp32 products on the fp16 matrix pipe, as in the GNN tile (split_f16 / mfma_split above).  One v_mfma_f32_16x16x32_f16 contracts a
+// K-BLOCK of 32 input features for a 16-row output block; an fp32 product is its four half products.  912 v_mfma_f32_16x16x4_f32 of 32+ cycles per
+// 16-sample tile became 456 of 16.  The WEIGHTS are split on the host (policies/mlp_model.py pack_mlp_params): the block keeps its size, every
+// 32-bit word now holds two fp16 halves.  The ACTIVATIONS are split once by their producer (the observation loader, the epilogue of a layer)
+// and pass through LDS already in B-operand form, hi and lo, one 16-byte read each per K-block.
+//   packed block (32-bit words): obs_mean NOBS | obs_inv_std NOBS | clip 1 (+3 pad) | W1q [16][KB1][64][8] | b1 256 | W2q [8][8][64][8] | b2 128 |
+//                 W3q [4][4][64][8] | b3 64 | Whq [1][2][64][8] (rows 0..11 mean, 12 value, 13..15 zero) | bh 16
+//   Wq [mb][kb][lane = n + 16 g][8]: words 0..3 = the fp16 hi halves of W[16 mb + n][col(kb, g, e)], e = 0..7, two per word (even e in the low
+//   half), words 4..7 the lo halves.  col = the input feature that k-slot (g, e) of K-block kb carries:
+//     layer 1 (observation, natural order):   col = 32 kb + 8 g + e            (columns >= NOBS are zero: 88 is padded to 96)
+//     later layers (a previous layer's output): col = 16 (2 kb + (e >> 2)) + 4 g + (e & 3)   = rows 4 g .. 4 g + 3 of output blocks 2 kb, 2 kb + 1,
+//   i.e. exactly what lane (n, g) of the producing MFMAs holds - a producer writes its four values where its consumer's lane (n, g) reads them.
+__host__ __device__ constexpr int mlp_kb1(int nobs) { return (nobs + 31) / 32; }
 __host__ __device__ constexpr int mlp_off_mean(int) { return 0; }
 __host__ __device__ constexpr int mlp_off_istd(int nobs) { return nobs; }
 __host__ __device__ constexpr int mlp_off_clip(int nobs) { return 2 * nobs; }
 __host__ __device__ constexpr int mlp_off_w1(int nobs) { return 2 * nobs + 4; }
-__host__ __device__ constexpr int mlp_off_b1(int nobs) { return mlp_off_w1(nobs) + 256 * nobs; }
+__host__ __device__ constexpr int mlp_off_b1(int nobs) { return mlp_off_w1(nobs) + 16 * mlp_kb1(nobs) * 512; }
 __host__ __device__ constexpr int mlp_off_w2(int nobs) { return mlp_off_b1(nobs) + 256; }
 __host__ __device__ constexpr int mlp_off_b2(int nobs) { return mlp_off_w2(nobs) + 128 * 256; }
 __host__ __device__ constexpr int mlp_off_w3(int nobs) { return mlp_off_b2(nobs) + 128; }
@@ -135,67 +144,120 @@ __host__ __device__ constexpr int mlp_off_wh(int nobs) { return mlp_off_b3(nobs)
 __host__ __device__ constexpr int mlp_off_bh(int nobs) { return mlp_off_wh(nobs) + 16 * 64; }
 __host__ __device__ constexpr int mlp_params(int nobs) { return mlp_off_bh(nobs) + 16; }
 
-// One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU: every layer's output blocks are dealt round-robin to the
-// wavefronts, activations pass from layer to layer through LDS as [feature][sample] (row stride 20 floats: the B-operand reads of the
-// four lane groups then fall on disjoint banks).  Weights are the MFMA A operand, pre-permuted on the host (policies/mlp_model.py).
-#define MLP_LDS_STRIDE 20
-// the observation tile is read in natural k order (rows 4 st + g): stride 16 puts the four lane groups on banks 0-15 / 16-31 / 32-47 / 48-63
-#define MLP_X_STRIDE 16
-#define MLP_IN_STRIDE(NATURAL) ((NATURAL) ? MLP_X_STRIDE : MLP_LDS_STRIDE)
-// k-row of the B operand for k-step `st`, lane group g: layer 1 reads the observation in natural order, the later layers in the order
-// the host permutation assumes (16 (st >> 2) + 4 g + (st & 3), i.e. "the previous layer's accumulator tile")
-template <bool NATURAL> __device__ __forceinline__ int mlp_krow(int st, int g) { return NATURAL ? 4 * st + g : 16 * (st >> 2) + 4 * g + (st & 3); }
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+// Activations in LDS, B-operand form: K-block kb, lane group g, sample n -> 8 words (hi halves of k-slots 0..7 | lo halves); consecutive samples
+// are 32 bytes apart, so the 16-byte reads of a group of eight lanes fall on disjoint banks.
+__device__ __forceinline__ int mlp_act_word(int kb, int g, int n) { return ((kb * 4 + g) * 16 + n) * 8; }
+// four consecutive k-slots (half = 0: e 0..3, half = 1: e 4..7) of one (kb, g, n): split and stored as two 8-byte writes
+__device__ __forceinline__ void mlp_store4(uint32_t* sAct, int kb, int g, int n, int half, float v0, float v1, float v2, float v3) {
+  const f32x2 a = {v0, v1}, b = {v2, v3};
+  const uint32_t h0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2)), h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2));
+  uint32_t l0, l1;
+  // (dst-sel forwarding hazard, see split_f16: one instruction between a mixlo and the mixhi on the same register, one wait state at the end)
+  asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0"
+      : "=&v"(l0), "=&v"(l1) : "v"(h0), "v"(h1), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+  uint32_t* p = sAct + mlp_act_word(kb, g, n) + 2 * half;
+  *reinterpret_cast<u32x2*>(p) = (u32x2){h0, h1};
+  *reinterpret_cast<u32x2*>(p + 4) = (u32x2){l0, l1};
+}
+__device__ __forceinline__ void mlp_load_b(const uint32_t* sAct, int kb, int g, int n, f16x8& bh, f16x8& bl) {
+  const uint32_t* p = sAct + mlp_act_word(kb, g, n);
+  bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p)); bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p + 4));
+}
+// epilogue of an output block mb (rows 4 g + k of sample n in acc): bias, activation, then into the next layer's B-operand form
+__device__ __forceinline__ void mlp_epilogue(uint32_t* sOut, int mb, int g, int n, const f32x4& acc, const float* b4) {
+  mlp_store4(sOut, mb >> 1, g, n, mb & 1, elu(acc[0] + b4[0]), elu(acc[1] + b4[1]), elu(acc[2] + b4[2]), elu(acc[3] + b4[3]));
+}
 
-// The k-steps of all output blocks a wavefront owns form one sequence, processed in chunks of MLP_CH with the NEXT chunk's weights
-// (one coalesced 256-byte load per k-step) in flight while the current chunk's MFMAs run.  Weights do not depend on activations, so
-// the prefetch also runs across the layer boundaries (the first chunk of layer L+1 is issued before layer L's last chunk is
-// computed and before the block barrier): the weight stream never drains and the kernel is bound by the matrix pipe, not by one
-// L2 round trip per chunk.
-#define MLP_CH 32
-#define MLP_RING 3      // register buffers of MLP_CH k-steps each: MLP_RING - 1 chunks in flight behind the MFMAs
-template <int OUT_BLOCKS, int IN_STEPS, bool NATURAL>
+#define MLP_O_STRIDE 20      // head outputs sO[row][sample] (fp32)
+template <int NOBS>
+struct MlpSmem { uint32_t sX[mlp_kb1(NOBS) * 512] __attribute__((aligned(16))), sH1[8 * 512] __attribute__((aligned(16))), sH2[4 * 512] __attribute__((aligned(16))),
+                 sH3[2 * 512] __attribute__((aligned(16))); float sO[16 * MLP_O_STRIDE], sLp[12 * 16]; };
+
+// normalised, clipped observation tile of samples s0 .. s0+15 into sX (B-operand form), by NT threads (t = 0 .. NT-1); features >= NOBS are zero
+template <int NOBS, bool LDS_OBS, int NT>
+__device__ __forceinline__ void mlp_load_obs(const float* obs, float obs_clip, int B, int s0, const float* __restrict__ W, uint32_t* sX, int t) {
+  constexpr int KP = 32 * mlp_kb1(NOBS);
+  for (int idx = t; idx < 16 * (KP / 4); idx += NT) {
+    const int sm = idx / (KP / 4), c0 = (idx - sm * (KP / 4)) * 4, sample = min(s0 + sm, B - 1);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < NOBS) {
+      float4 o4;
+      if (LDS_OBS) {
+        o4 = *reinterpret_cast<const float4*>(obs + sm * NOBS + c0);
+        o4.x = fminf(fmaxf(o4.x, -obs_clip), obs_clip); o4.y = fminf(fmaxf(o4.y, -obs_clip), obs_clip);
+        o4.z = fminf(fmaxf(o4.z, -obs_clip), obs_clip); o4.w = fminf(fmaxf(o4.w, -obs_clip), obs_clip);
+      } else {
+        o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * NOBS + c0);
+      }
+      const float clip = W[mlp_off_clip(NOBS)], o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = fminf(fmaxf((o[i] - W[mlp_off_mean(NOBS) + c0 + i]) * W[mlp_off_istd(NOBS) + c0 + i], -clip), clip);
+    }
+    mlp_store4(sX, c0 >> 5, (c0 & 31) >> 3, sm, (c0 & 7) >> 2, v[0], v[1], v[2], v[3]);
+  }
+}
+
+// One block = 16 samples on the 4 wavefronts (= 4 SIMDs) of a CU: every layer's output blocks are dealt round-robin to the wavefronts (block
+// mb = wave + 4 j).  A wavefront's weights form one sequence of ITEMS - (output block, K-block) pairs, 8 words per lane, K-block-major within a
+// layer so that one B operand read serves all the blocks the wavefront owns - streamed in chunks of MLP_CH items with MLP_RING - 1 chunks in
+// flight behind the MFMAs, across the layer boundaries (weights do not depend on activations).
+#ifndef MLP_CH
+#define MLP_CH 4
+#endif
+#ifndef MLP_RING
+#define MLP_RING 3
+#endif
+template <int OUT_BLOCKS, int KB>
 struct MlpLayer {
-  static constexpr int OWNED = (OUT_BLOCKS + 3) / 4, TOTAL = OWNED * IN_STEPS, NCH = (TOTAL + MLP_CH - 1) / MLP_CH;
+  static constexpr int OWNED = (OUT_BLOCKS + 3) / 4, TOTAL = OWNED * KB, NCH = (TOTAL + MLP_CH - 1) / MLP_CH;
   static constexpr bool FULL = (OUT_BLOCKS % 4) == 0;       // every wavefront owns exactly OWNED output blocks (else: only wavefront 0 calls)
-  // weights of chunk c of this wavefront's k-step sequence -> dst (registers)
-  static __device__ __forceinline__ void issue(const float* __restrict__ Wp, int wave, int lane, int c, float* dst) {
+  // item s of the wavefront's sequence: K-block kb = s / OWNED, owned block j = s % OWNED
+  static __device__ __forceinline__ void issue(const float* __restrict__ Wq, int wave, int lane, int c, u32x4* dst) {
 #pragma unroll
     for (int i = 0; i < MLP_CH; i++) {
       const int s = c * MLP_CH + i;
-      if (s < TOTAL) { const int j = s / IN_STEPS, st = s - j * IN_STEPS, mb = wave + 4 * j; dst[i] = Wp[((size_t)mb * IN_STEPS + st) * 64 + lane]; }
+      if (s < TOTAL) {
+        const int kb = s / OWNED, j = s - kb * OWNED, mb = wave + 4 * j;
+        const u32x4* src = reinterpret_cast<const u32x4*>(Wq + ((size_t)(mb * KB + kb) * 64 + lane) * 8);
+        dst[2 * i] = src[0]; dst[2 * i + 1] = src[1];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the whole chunk's loads ahead of the MFMAs that follow (the scheduler would sink them to their uses)
   }
-  // this lane's bias values (4 per owned output block); loaded once at kernel start: a load issued behind the weight prefetch would
-  // make its consumer wait for the whole prefetch (vmcnt counts in order)
   static __device__ __forceinline__ void load_bias(const float* __restrict__ bias, int wave, int g, float* dst) {
 #pragma unroll
     for (int j = 0; j < OWNED; j++)
 #pragma unroll
       for (int k = 0; k < 4; k++) dst[4 * j + k] = bias[16 * (wave + 4 * j) + 4 * g + k];
   }
-  // MFMAs of chunk c; the accumulator carries over between the chunks of one output block
-  static __device__ __forceinline__ void compute(const float* breg, const float* sIn, float* sOut, int wave, int n, int g, bool act,
-                                                 int c, const float* a, f32x4& acc) {
+  // MFMAs of chunk c; acc[j] carries over between the chunks of a layer.  LAST = the head: plain fp32 rows into sO, no activation
+  template <bool LAST>
+  static __device__ __forceinline__ void compute(const float* breg, const uint32_t* sIn, uint32_t* sOut, float* sO, int wave, int n, int g, int c, const u32x4* a, f32x4* acc) {
+    f16x8 bh, bl;
 #pragma unroll
     for (int i = 0; i < MLP_CH; i++) {
       const int s = c * MLP_CH + i;
       if (s < TOTAL) {
-        const int j = s / IN_STEPS, st = s - j * IN_STEPS, mb = wave + 4 * j;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], sIn[mlp_krow<NATURAL>(st, g) * MLP_IN_STRIDE(NATURAL) + n], acc, 0, 0, 0);
-        if (st == IN_STEPS - 1) {
+        const int kb = s / OWNED, j = s - kb * OWNED, mb = wave + 4 * j;
+        if (j == 0 || i == 0) mlp_load_b(sIn, kb, g, n, bh, bl);
+        if (kb == 0) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[j] = mfma_split(__builtin_bit_cast(f16x8, a[2 * i]), __builtin_bit_cast(f16x8, a[2 * i + 1]), bh, bl, acc[j]);
+        if (kb == KB - 1) {
+          if (LAST) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) { float v = acc[k] + breg[4 * j + k]; sOut[(16 * mb + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
-          acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 4; k++) sO[(4 * g + k) * MLP_O_STRIDE + n] = acc[j][k] + breg[4 * j + k];
+          } else mlp_epilogue(sOut, mb, g, n, acc[j], breg + 4 * j);
         }
       }
     }
   }
 };
-
-
-template <int NOBS>
-struct MlpSmem { float sX[NOBS * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2[128 * MLP_LDS_STRIDE], sH3[64 * MLP_LDS_STRIDE], sO[16 * MLP_LDS_STRIDE], sLp[12 * 16]; };
 
 // Forward pass of samples s0 .. s0+15 by the 256 threads of a block (t = thread index in the block; contains block barriers).
 // LDS_OBS = false: `obs` is the global (B, NOBS) observation matrix.  LDS_OBS = true: `obs` is a [16][NOBS] tile in LDS holding the
@@ -204,68 +266,50 @@ struct MlpSmem { float sX[NOBS * MLP_LDS_STRIDE], sH1[256 * MLP_LDS_STRIDE], sH2
 template <int NOBS, bool LDS_OBS>
 __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int B, int s0, const float* __restrict__ W, float* __restrict__ mean,
                                           float* __restrict__ value, const SampleArgs& SA, MlpSmem<NOBS>& M, int t) {
-  float *sX = M.sX, *sH1 = M.sH1, *sH2 = M.sH2, *sH3 = M.sH3, *sO = M.sO;
   const int wave = t >> 6, lane = t & 63, n = lane & 15, g = lane >> 4;
-  typedef MlpLayer<16, NOBS / 4, true> L1; typedef MlpLayer<8, 64, false> L2; typedef MlpLayer<4, 32, false> L3; typedef MlpLayer<1, 16, false> L4;
+  typedef MlpLayer<16, mlp_kb1(NOBS)> L1; typedef MlpLayer<8, 8> L2; typedef MlpLayer<4, 4> L3; typedef MlpLayer<1, 2> L4;
   static_assert(L1::FULL && L2::FULL && L3::FULL && !L4::FULL, "wavefront ownership");
   const float *W1 = W + mlp_off_w1(NOBS), *W2 = W + mlp_off_w2(NOBS), *W3 = W + mlp_off_w3(NOBS), *W4 = W + mlp_off_wh(NOBS);
   float br1[4 * L1::OWNED], br2[4 * L2::OWNED], br3[4 * L3::OWNED], br4[4];
   L1::load_bias(W + mlp_off_b1(NOBS), wave, g, br1); L2::load_bias(W + mlp_off_b2(NOBS), wave, g, br2);
   L3::load_bias(W + mlp_off_b3(NOBS), wave, g, br3); L4::load_bias(W + mlp_off_bh(NOBS), 0, g, br4);
-  // normalised, clipped observation tile: one 16-byte load per (sample, 4 features)
-  for (int idx = t; idx < 16 * (NOBS / 4); idx += 256) {
-    const int sm = idx / (NOBS / 4), c0 = (idx - sm * (NOBS / 4)) * 4, sample = min(s0 + sm, B - 1);
-    float4 o4;
-    if (LDS_OBS) {
-      o4 = *reinterpret_cast<const float4*>(obs + sm * NOBS + c0);
-      o4.x = fminf(fmaxf(o4.x, -obs_clip), obs_clip); o4.y = fminf(fmaxf(o4.y, -obs_clip), obs_clip);
-      o4.z = fminf(fmaxf(o4.z, -obs_clip), obs_clip); o4.w = fminf(fmaxf(o4.w, -obs_clip), obs_clip);
-    } else {
-      o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * NOBS + c0);
-    }
-    const float clip = W[mlp_off_clip(NOBS)], o[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float v = (o[i] - W[mlp_off_mean(NOBS) + c0 + i]) * W[mlp_off_istd(NOBS) + c0 + i];
-      sX[(c0 + i) * MLP_X_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
-    }
-  }
-  // The chunks of all layers form one sequence s = 0 .. NS-1 (the head's single chunk last, wavefront 0 only); chunk s+2 is issued before chunk
-  // s is computed, into a ring of three register buffers: two chunks (16 KB per wavefront) are in flight behind the MFMAs, because one
-  // chunk's 32 MFMAs (about 1000 cycles) do not cover an L2 round trip under the load of 1024 streaming wavefronts.
+  mlp_load_obs<NOBS, LDS_OBS, 256>(obs, obs_clip, B, s0, W, M.sX, t);
+  // The chunks of all layers form one sequence sq = 0 .. NB-1 (the head's single chunk last, wavefront 0 only); chunk sq + MLP_RING - 1 is issued
+  // before chunk sq is computed, into a ring of register buffers.
   constexpr int N1 = L1::NCH, N2 = L2::NCH, N3 = L3::NCH, NB = N1 + N2 + N3;
-  auto issue = [&](int sq, float* dst) {
+  auto issue = [&](int sq, u32x4* dst) {
     if (sq < N1) L1::issue(W1, wave, lane, sq, dst);
     else if (sq < N1 + N2) L2::issue(W2, wave, lane, sq - N1, dst);
     else if (sq < NB) L3::issue(W3, wave, lane, sq - N1 - N2, dst);
     else if (sq == NB && wave == 0) L4::issue(W4, 0, lane, 0, dst);
   };
   MLP_STAMP(0);      // biases, observation tile
-  float abuf[MLP_RING][MLP_CH];
+  u32x4 abuf[MLP_RING][2 * MLP_CH];
 #pragma unroll
   for (int sq = 0; sq < MLP_RING - 1; sq++) issue(sq, abuf[sq]);
   lds_barrier();
-  MLP_STAMP(1);      // first two chunks issued, barrier
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  MLP_STAMP(1);      // first chunks issued, barrier
+  f32x4 acc[4];
 #pragma unroll
   for (int sq = 0; sq < NB; sq++) {
     issue(sq + MLP_RING - 1, abuf[(sq + MLP_RING - 1) % MLP_RING]);
-    if (sq < N1) L1::compute(br1, sX, sH1, wave, n, g, true, sq, abuf[sq % MLP_RING], acc);
-    else if (sq < N1 + N2) L2::compute(br2, sH1, sH2, wave, n, g, true, sq - N1, abuf[sq % MLP_RING], acc);
-    else L3::compute(br3, sH2, sH3, wave, n, g, true, sq - N1 - N2, abuf[sq % MLP_RING], acc);
+    if (sq < N1) L1::template compute<false>(br1, M.sX, M.sH1, M.sO, wave, n, g, sq, abuf[sq % MLP_RING], acc);
+    else if (sq < N1 + N2) L2::template compute<false>(br2, M.sH1, M.sH2, M.sO, wave, n, g, sq - N1, abuf[sq % MLP_RING], acc);
+    else L3::template compute<false>(br3, M.sH2, M.sH3, M.sO, wave, n, g, sq - N1 - N2, abuf[sq % MLP_RING], acc);
     MLP_STAMP(2 + (sq < N1 ? 0 : sq < N1 + N2 ? 2 : 4));      // compute of a layer's chunks
     if (sq == N1 - 1 || sq == N1 + N2 - 1 || sq == NB - 1) { lds_barrier(); MLP_STAMP(3 + (sq < N1 ? 0 : sq < N1 + N2 ? 2 : 4)); }      // its barrier
   }
   if (wave != 0) return;
-  L4::compute(br4, sH3, sO, 0, n, g, false, 0, abuf[NB % MLP_RING], acc);
+  L4::template compute<true>(br4, M.sH3, nullptr, M.sO, 0, n, g, 0, abuf[NB % MLP_RING], acc);
   __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+  const float* sO = M.sO;
   const int smp = s0 + n;
   const bool valid = smp < B;
   float lp = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int j = 4 * g + i;                      // head output row: 0..11 action means, 12 value
-    const float v = sO[j * MLP_LDS_STRIDE + n];
+    const float v = sO[j * MLP_O_STRIDE + n];
     if (valid && j < 12 && mean) mean[(size_t)smp * 12 + j] = v;
     if (valid && j == 12) value[smp] = v;
     if (SA.log_std && j < 12 && valid) {
@@ -279,64 +323,48 @@ __device__ __forceinline__ void mlp_block(const float* obs, float obs_clip, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// MLP tile with RESIDENT weights (persistent rollout kernel, lm_engine.hip k_rollout_mlp).  The streaming tile above spends half of its time
-// waiting for its 233 KB of weights (all 256 compute units read the same rows at the same time), every step again.  In the persistent kernel
-// wavefront 0 steps the physics and the other three - the policy wavefronts P = 0, 1, 2 - are idle meanwhile with 512 registers per lane each:
-// they load every weight ONCE per rollout and keep it in registers (320 / 304 / 288 per lane), so a forward is MFMAs and LDS traffic only.
-// Output blocks are dealt to the policy wavefronts round-robin (layer 3: {0}, {1}, {2, 3}; the head, 16 MFMAs, is computed by each of them, so
-// that the action sampling - a Philox draw, a logarithm and a sine / cosine per action - is spread over all 192 lanes, one action each);
-// the k-step order inside an output block is that of the streaming tile, so both produce the same bits.
+// MLP tile with RESIDENT weights (persistent rollout kernel, lm_engine.hip k_rollout_mlp).  In the persistent kernel wavefront 0 steps the
+// physics and the other three - the policy wavefronts P = 0, 1, 2 - are idle meanwhile with 512 registers per lane each: they load every weight
+// ONCE per rollout and keep it in registers (320 / 304 / 288 words per lane), so a forward is MFMAs and LDS traffic only.  Output blocks are dealt
+// to the policy wavefronts round-robin (layer 3: {0}, {1}, {2, 3}; the head is computed by each of them, so that the action sampling - a Philox
+// draw, a logarithm and a sine / cosine per action - is spread over all 192 lanes, one action each); an output block accumulates its K-blocks in
+// the order of the streaming tile, each as lo.lo + lo.hi + hi.lo + hi.hi, so both tiles produce the same bits.
 template <int P, int OUT_BLOCKS, bool LAYER3> struct ResOwn {
-  static constexpr int CNT = LAYER3 ? (P == 2 ? 2 : 1) : (OUT_BLOCKS == 1 ? 1 : (OUT_BLOCKS - P + 2) / 3);      // the head (one block, 16 k-steps) is computed by all three
+  static constexpr int CNT = LAYER3 ? (P == 2 ? 2 : 1) : (OUT_BLOCKS == 1 ? 1 : (OUT_BLOCKS - P + 2) / 3);      // the head (one block) is computed by all three
   static __device__ __forceinline__ constexpr int mb(int j) { return LAYER3 ? (P == 2 ? 2 + j : P) : (OUT_BLOCKS == 1 ? 0 : P + 3 * j); }
 };
-template <int P, int OUT_BLOCKS, int IN_STEPS, bool NATURAL, bool LAYER3>
+template <int P, int OUT_BLOCKS, int KB, bool LAYER3>
 struct ResLayer {
   typedef ResOwn<P, OUT_BLOCKS, LAYER3> O;
-  static constexpr int CNT = O::CNT, NW = (CNT * IN_STEPS > 0) ? CNT * IN_STEPS : 1, NBR = CNT > 0 ? 4 * CNT : 1;
-  static __device__ __forceinline__ void load(const float* __restrict__ Wp, const float* __restrict__ bias, int lane, int g, float* w, float* br) {
+  static constexpr int CNT = O::CNT, NW = (CNT * KB > 0) ? 2 * CNT * KB : 1, NBR = CNT > 0 ? 4 * CNT : 1;
+  static __device__ __forceinline__ void load(const float* __restrict__ Wq, const float* __restrict__ bias, int lane, int g, u32x4* w, float* br) {
 #pragma unroll
     for (int j = 0; j < CNT; j++) {
 #pragma unroll
-      for (int st = 0; st < IN_STEPS; st++) w[j * IN_STEPS + st] = Wp[((size_t)O::mb(j) * IN_STEPS + st) * 64 + lane];
+      for (int kb = 0; kb < KB; kb++) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(Wq + ((size_t)(O::mb(j) * KB + kb) * 64 + lane) * 8);
+        w[2 * (j * KB + kb)] = src[0]; w[2 * (j * KB + kb) + 1] = src[1];
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) br[4 * j + k] = bias[16 * O::mb(j) + 4 * g + k];
     }
   }
-  static __device__ __forceinline__ void compute(const float* w, const float* br, const float* sIn, float* sOut, int n, int g, bool act) {
+  static __device__ __forceinline__ void compute(const u32x4* w, const float* br, const uint32_t* sIn, uint32_t* sOut, int n, int g) {
     // the layer's input (the B operands of every output block) in registers first: read where they are used, each LDS round trip is exposed
-    // behind two k-steps of MFMAs (48 cycles per MFMA measured instead of 32)
-    float bv[IN_STEPS];
+    f16x8 bh[KB], bl[KB];
 #pragma unroll
-    for (int st = 0; st < IN_STEPS; st++) bv[st] = sIn[mlp_krow<NATURAL>(st, g) * MLP_IN_STRIDE(NATURAL) + n];
+    for (int kb = 0; kb < KB; kb++) mlp_load_b(sIn, kb, g, n, bh[kb], bl[kb]);
     __builtin_amdgcn_sched_barrier(0);
-    // The resident weights sit in accumulation registers; an MFMA issued right behind the v_accvgpr_read that fetches its A operand stalls
-    // on it (60 cycles per MFMA instead of 34, tools/microbench/mfma_chains.hip "valu-fed").  So the weights of GRP k-steps of all the
-    // wavefront's output blocks are moved to ordinary registers in one batch, then their MFMAs issue with nothing in between.
-    constexpr int GRP = (CNT > 3) ? ((IN_STEPS % 8 == 0) ? 8 : 11) : ((IN_STEPS % 16 == 0) ? 16 : ((IN_STEPS % 11 == 0) ? 11 : 8));      // at most 48 staged weights
-    static_assert(IN_STEPS % GRP == 0, "k-step groups");
     f32x4 acc[CNT > 0 ? CNT : 1];
 #pragma unroll
     for (int j = 0; j < CNT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s0 = 0; s0 < IN_STEPS; s0 += GRP) {
-      float ws[CNT > 0 ? CNT : 1][GRP];
+    for (int kb = 0; kb < KB; kb++)
 #pragma unroll
       for (int j = 0; j < CNT; j++)
+        acc[j] = mfma_split(__builtin_bit_cast(f16x8, w[2 * (j * KB + kb)]), __builtin_bit_cast(f16x8, w[2 * (j * KB + kb) + 1]), bh[kb], bl[kb], acc[j]);
 #pragma unroll
-        for (int i = 0; i < GRP; i++) { ws[j][i] = w[j * IN_STEPS + s0 + i]; if (CNT <= 3) asm volatile("" : "+v"(ws[j][i])); }      // (layer 1, 5-6 blocks of 16 k-steps: staging costs more registers than it saves stalls)
-      if (CNT <= 3) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < GRP; i++)
-#pragma unroll
-        for (int j = 0; j < CNT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j][i], bv[s0 + i], acc[j], 0, 0, 0);
-      if (CNT <= 3) __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < CNT; j++) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const float v = acc[j][k] + br[4 * j + k]; sOut[(16 * O::mb(j) + 4 * g + k) * MLP_LDS_STRIDE + n] = act ? elu(v) : v; }
-    }
+    for (int j = 0; j < CNT; j++) mlp_epilogue(sOut, O::mb(j), g, n, acc[j], br + 4 * j);
   }
 };
 #ifndef MLP_RES_STAMP
@@ -345,8 +373,8 @@ struct ResLayer {
 #define MLP_RES_BARRIERS 5      // block barriers inside one resident tile; the physics wavefront executes the same number while the tile runs
 
 template <int NOBS, int P> struct MlpResRegs {
-  typedef ResLayer<P, 16, NOBS / 4, true, false> L1; typedef ResLayer<P, 8, 64, false, false> L2; typedef ResLayer<P, 4, 32, false, true> L3; typedef ResLayer<P, 1, 16, false, false> L4;
-  float w1[L1::NW], w2[L2::NW], w3[L3::NW], w4[L4::NW], b1[L1::NBR], b2[L2::NBR], b3[L3::NBR], b4[L4::NBR];
+  typedef ResLayer<P, 16, mlp_kb1(NOBS), false> L1; typedef ResLayer<P, 8, 8, false> L2; typedef ResLayer<P, 4, 4, true> L3; typedef ResLayer<P, 1, 2, false> L4;
+  u32x4 w1[L1::NW], w2[L2::NW], w3[L3::NW], w4[L4::NW]; float b1[L1::NBR], b2[L2::NBR], b3[L3::NBR], b4[L4::NBR];
   __device__ __forceinline__ void load(const float* __restrict__ W, int lane, int g) {
     L1::load(W + mlp_off_w1(NOBS), W + mlp_off_b1(NOBS), lane, g, w1, b1); L2::load(W + mlp_off_w2(NOBS), W + mlp_off_b2(NOBS), lane, g, w2, b2);
     L3::load(W + mlp_off_w3(NOBS), W + mlp_off_b3(NOBS), lane, g, w3, b3); L4::load(W + mlp_off_wh(NOBS), W + mlp_off_bh(NOBS), lane, g, w4, b4);
@@ -358,48 +386,31 @@ template <int NOBS, int P, bool LDS_OBS>
 __device__ __forceinline__ void mlp_res_tile(const float* obs, float obs_clip, int B, int s0, const float* __restrict__ W, const MlpResRegs<NOBS, P>& R,
                                              float* __restrict__ value, const SampleArgs& SA, MlpSmem<NOBS>& M, int tp) {
   typedef MlpResRegs<NOBS, P> RG;
-  float *sX = M.sX, *sH1 = M.sH1, *sH2 = M.sH2, *sH3 = M.sH3, *sO = M.sO;
   const int lane = tp & 63, n = lane & 15, g = lane >> 4;
-  for (int idx = tp; idx < 16 * (NOBS / 4); idx += 192) {
-    const int sm = idx / (NOBS / 4), c0 = (idx - sm * (NOBS / 4)) * 4, sample = min(s0 + sm, B - 1);
-    float4 o4;
-    if (LDS_OBS) {
-      o4 = *reinterpret_cast<const float4*>(obs + sm * NOBS + c0);
-      o4.x = fminf(fmaxf(o4.x, -obs_clip), obs_clip); o4.y = fminf(fmaxf(o4.y, -obs_clip), obs_clip);
-      o4.z = fminf(fmaxf(o4.z, -obs_clip), obs_clip); o4.w = fminf(fmaxf(o4.w, -obs_clip), obs_clip);
-    } else {
-      o4 = *reinterpret_cast<const float4*>(obs + (size_t)sample * NOBS + c0);
-    }
-    const float clip = W[mlp_off_clip(NOBS)], o[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float v = (o[i] - W[mlp_off_mean(NOBS) + c0 + i]) * W[mlp_off_istd(NOBS) + c0 + i];
-      sX[(c0 + i) * MLP_X_STRIDE + sm] = fminf(fmaxf(v, -clip), clip);
-    }
-  }
+  mlp_load_obs<NOBS, LDS_OBS, 192>(obs, obs_clip, B, s0, W, M.sX, tp);
   MLP_RES_STAMP(P, 0);      // wait for the physics + observation tile
   lds_barrier();
   MLP_RES_STAMP(P, 1);
-  RG::L1::compute(R.w1, R.b1, sX, sH1, n, g, true);
+  RG::L1::compute(R.w1, R.b1, M.sX, M.sH1, n, g);
   MLP_RES_STAMP(P, 2);
   lds_barrier();
   MLP_RES_STAMP(P, 3);
-  RG::L2::compute(R.w2, R.b2, sH1, sH2, n, g, true);
+  RG::L2::compute(R.w2, R.b2, M.sH1, M.sH2, n, g);
   MLP_RES_STAMP(P, 4);
   lds_barrier();
   MLP_RES_STAMP(P, 5);
-  RG::L3::compute(R.w3, R.b3, sH2, sH3, n, g, true);
+  RG::L3::compute(R.w3, R.b3, M.sH2, M.sH3, n, g);
   MLP_RES_STAMP(P, 6);
   lds_barrier();
   MLP_RES_STAMP(P, 7);
   {
     // head: rows 0..11 action means, 12 value; lane (n, g) holds rows 4g .. 4g+3 of sample n
-    float bv[16];
-#pragma unroll
-    for (int st = 0; st < 16; st++) bv[st] = sH3[mlp_krow<false>(st, g) * MLP_LDS_STRIDE + n];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int st = 0; st < 16; st++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.w4[st], bv[st], acc, 0, 0, 0);
+    for (int kb = 0; kb < 2; kb++) {
+      f16x8 bh, bl; mlp_load_b(M.sH3, kb, g, n, bh, bl);
+      acc = mfma_split(__builtin_bit_cast(f16x8, R.w4[2 * kb]), __builtin_bit_cast(f16x8, R.w4[2 * kb + 1]), bh, bl, acc);
+    }
     float hv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) hv[k] = acc[k] + R.b4[k];

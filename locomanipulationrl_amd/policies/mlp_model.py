@@ -1,6 +1,7 @@
 """MLP policy of the reference's PPO scripts (scripts/skrl_ppo_locomotion.py:25-52): shared trunk 64-256-128-64 (ELU),
 Gaussian mean head (12), value head (1), log-std parameter; plus the matrix-core forward for rollouts with skrl's
-RunningStandardScaler observation preprocessor folded in (:96-99)."""
+RunningStandardScaler observation preprocessor folded in (:96-99).  The forward computes its fp32 products on the fp16 matrix pipe with every
+operand split into two fp16 halves (fp32-level accuracy): the weights are split here, on the host (`_pack_q`)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -33,16 +34,27 @@ class SharedMLP(nn.Module):
         self._packed = pack_mlp_params(self, obs_mean, obs_var, eps, clip).to(device or self.log_std_parameter.device)
 
 
-def _permute(W: torch.Tensor, natural_k: bool) -> torch.Tensor:
-    """(out, in) weight -> [out/16][in/4][64] in the lane order v_mfma_f32_16x16x4_f32 reads its A operand:
-    lane l supplies row 16*mb + (l & 15); its k index is 4*step + (l >> 4) for an input in natural order, and
-    16*(step >> 2) + 4*(l >> 4) + (step & 3) for an input that is a previous layer's accumulator tile."""
+def _pack_q(W: torch.Tensor, natural_k: bool) -> torch.Tensor:
+    """(out, in) fp32 weight -> the 32-bit words [out/16][KB][64 lanes][8] the MLP tile reads (csrc/lm_policy_dev.h): for output block mb,
+    K-block kb (32 input features) and lane l = n + 16 g, the eight weights W[16 mb + n][col(kb, g, e)], e = 0..7, each split into two fp16
+    halves (w = hi + lo, hi = fp16(w), lo = fp16(w - hi)): words 0..3 hold the hi halves (two per word, even e in the low 16 bits), words 4..7
+    the lo halves.  col = 32 kb + 8 g + e for an input in natural order (the observation; columns beyond `in` are zero: 88 pads to 96), and
+    16 (2 kb + (e >> 2)) + 4 g + (e & 3) for an input that is a previous layer's accumulator tile."""
     out_f, in_f = W.shape
-    lane = torch.arange(64); n, g = lane & 15, lane >> 4
-    mb = torch.arange(out_f // 16).view(-1, 1, 1); st = torch.arange(in_f // 4).view(1, -1, 1)
-    row = 16 * mb + n.view(1, 1, -1)
-    col = (4 * st + g.view(1, 1, -1)) if natural_k else (16 * (st // 4) + 4 * g.view(1, 1, -1) + (st % 4))
-    return W[row.expand(-1, in_f // 4, -1), col.expand(out_f // 16, -1, -1)].reshape(-1)
+    KB = (in_f + 31) // 32
+    Wp = torch.zeros(out_f, 32 * KB, dtype=torch.float32, device=W.device); Wp[:, :in_f] = W.float()
+    lane = torch.arange(64, device=W.device); n, g = lane & 15, lane >> 4
+    mb = torch.arange(out_f // 16, device=W.device).view(-1, 1, 1, 1); kb = torch.arange(KB, device=W.device).view(1, -1, 1, 1)
+    e = torch.arange(8, device=W.device).view(1, 1, 1, -1); nn, gg = n.view(1, 1, -1, 1), g.view(1, 1, -1, 1)
+    row = (16 * mb + nn).expand(-1, KB, -1, 8)
+    col = (32 * kb + 8 * gg + e) if natural_k else (16 * (2 * kb + (e >> 2)) + 4 * gg + (e & 3))
+    w = Wp[row, col.expand(out_f // 16, -1, -1, -1)]                                   # [mb][kb][lane][e]
+    hi = w.half(); lo = (w - hi.float()).half()                                          # round to nearest even, like the device's v_cvt_pk_f16_f32
+    def pairs(h):                                                                        # fp16 [.., 8] -> int32 [.., 4]: even e in the low half
+        u = h.view(torch.int16).to(torch.int32) & 0xFFFF
+        return u[..., 0::2] | (u[..., 1::2] << 16)
+    words = torch.cat([pairs(hi), pairs(lo)], dim=-1).contiguous()                       # [mb][kb][lane][8]
+    return words.view(torch.float32).reshape(-1)                                         # bit patterns in a float32 tensor (never used as numbers)
 
 
 def pack_mlp_params(m: SharedMLP, obs_mean=None, obs_var=None, eps=1e-8, clip=5.0) -> torch.Tensor:
@@ -56,8 +68,8 @@ def pack_mlp_params(m: SharedMLP, obs_mean=None, obs_var=None, eps=1e-8, clip=5.
     l1, l2, l3 = m.net[0], m.net[2], m.net[4]
     Wh = torch.zeros(16, 64, device=dev); Wh[:12] = m.mean_layer.weight.detach(); Wh[12] = m.value_layer.weight.detach()[0]
     bh = torch.zeros(16, device=dev); bh[:12] = m.mean_layer.bias.detach(); bh[12] = m.value_layer.bias.detach()[0]
-    parts = [mean, istd, clipv, _permute(l1.weight.detach(), True), l1.bias.detach(), _permute(l2.weight.detach(), False), l2.bias.detach(),
-             _permute(l3.weight.detach(), False), l3.bias.detach(), _permute(Wh, False), bh]
+    parts = [mean, istd, clipv, _pack_q(l1.weight.detach(), True), l1.bias.detach(), _pack_q(l2.weight.detach(), False), l2.bias.detach(),
+             _pack_q(l3.weight.detach(), False), l3.bias.detach(), _pack_q(Wh, False), bh]
     return torch.cat([p.reshape(-1).float() for p in parts]).contiguous()
 
 
