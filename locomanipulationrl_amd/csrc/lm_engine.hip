@@ -1859,7 +1859,7 @@ static void derive_params(lm_params* p) {
 extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
-const char* lm_version(void) { return "lm_engine 0.4 (gfx950, abi 4)"; }
+const char* lm_version(void) { return "lm_engine 0.5 (gfx950, abi 4, policy tiles on the fp16 matrix pipe)"; }
 int lm_abi_version(void) { return LM_ABI_VERSION; }
 
 int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* params, int n_tasks, int split_env, uint32_t seed) {

@@ -96,6 +96,9 @@ def pack_gnn_params(net: GraphNet, mean_layer: Action_Layer, value_layer: Value_
     for gl in (net.graph_layer1, net.graph_layer2, net.graph_layer3):
         parts += [gl.linear1.weight, gl.linear1.bias, gl.linear2.weight, gl.linear2.bias]
     parts += [mean_layer.action_layer.weight, mean_layer.action_layer.bias, value_layer.action_layer.weight, value_layer.action_layer.bias]
+    for q in parts:      # the tile splits every fp32 operand into two fp16 halves (csrc/lm_policy_dev.h): weights must be inside the fp16 range
+        if not bool(torch.isfinite(q).all()) or float(q.detach().abs().max()) >= 6.0e4:
+            raise ValueError("GNN weights must be finite and below the fp16 range (6e4) for the split-fp16 matrix products")
     dev = net.input_layer1.weight.device
     parts += [torch.zeros(64, device=dev) if obs_mean is None else obs_mean.to(dev),
               torch.ones(64, device=dev) if obs_var is None else 1.0 / (obs_var.to(dev).float().sqrt() + eps),

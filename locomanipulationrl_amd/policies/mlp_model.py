@@ -49,6 +49,8 @@ def _pack_q(W: torch.Tensor, natural_k: bool) -> torch.Tensor:
     row = (16 * mb + nn).expand(-1, KB, -1, 8)
     col = (32 * kb + 8 * gg + e) if natural_k else (16 * (2 * kb + (e >> 2)) + 4 * gg + (e & 3))
     w = Wp[row, col.expand(out_f // 16, -1, -1, -1)]                                   # [mb][kb][lane][e]
+    if not bool(torch.isfinite(w).all()) or float(w.abs().max()) >= 6.0e4:
+        raise ValueError("MLP weights must be finite and below the fp16 range (6e4) for the split-fp16 matrix products")
     hi = w.half(); lo = (w - hi.float()).half()                                          # round to nearest even, like the device's v_cvt_pk_f16_f32
     def pairs(h):                                                                        # fp16 [.., 8] -> int32 [.., 4]: even e in the low half
         u = h.view(torch.int16).to(torch.int32) & 0xFFFF

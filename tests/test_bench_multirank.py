@@ -32,3 +32,23 @@ def test_bench_two_ranks_over_gloo():
     assert r["value"] > 0 and abs(r["value"] - 8192 * 96 / (r["ms_per_step"] * 96e-3)) / r["value"] < 1e-6
     assert r["roofline"]["kernel_ms"] > 0 and r["roofline"]["step_period_ms"] >= r["roofline"]["kernel_ms"]
     assert "cpu_baseline" not in r                              # N > 1: rank 0 does not time the CPU
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_run_on_this_box():
+    """backend "nccl" IS RCCL on ROCm.  Two RCCL ranks cannot share the one GPU of the test box, so the library itself is exercised with a
+    one-rank group in a fresh child process: process-group init on the device, the (2, 48, N) all-gather of bench.py / distributed.all_gather_rollout
+    and the all-reduce of the PPO harness on device tensors.  Catches an image or environment in which RCCL cannot start (e.g. the IPC mode
+    variable the pool needs) before the driver's 8-GPU run does."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1)\n"
+        "x = torch.arange(2 * 48 * 4096, device='cuda', dtype=torch.float32).reshape(2, 48, 4096); out = torch.empty(2, 48, 4096, device='cuda')\n"
+        "dist.all_gather_into_tensor(out, x); g = torch.ones(58649, device='cuda'); dist.all_reduce(g); dist.barrier(device_ids=[0]); torch.cuda.synchronize()\n"
+        "assert torch.equal(out, x) and float(g.sum()) == 58649.0\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, p.stderr[-2000:]

@@ -315,3 +315,61 @@ def test_gnn_backward_is_the_plain_per_node_backward():
     g1, = torch.autograd.grad(ta[0, 5].sum(), ht, retain_graph=True); g2, = torch.autograd.grad(tb[0, 5].sum(), ht)
     assert float((g1[0, 1] + g1[0, 9] - g2[0, 1] - g2[0, 9]).abs().max()) < 1e-12          # same total; amax halves it between the tied sources
     assert float((g1[0, 1] - g1[0, 9]).abs().max()) < 1e-12
+
+
+def test_mlp_weight_packing_is_a_lossless_enough_permutation():
+    """pack_mlp_params (round 4): every weight matrix becomes 32-bit words [out/16][K-block][lane][hi 4 | lo 4] in the operand order of
+    v_mfma_f32_16x16x32_f16, each weight split into two fp16 halves.  Unpacking with the column map of csrc/lm_policy_dev.h gives back W to 2^-21
+    relative (the split carries 22 bits), for the natural-order first layer (88 columns padded to 96 with zeros) and for an accumulator-order layer;
+    block sizes are those the kernel's offset table assumes."""
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, _pack_q, pack_mlp_params
+    torch.manual_seed(3)
+    for out_f, in_f, natural in ((256, 88, True), (256, 64, True), (128, 256, False), (16, 64, False)):
+        W = torch.randn(out_f, in_f) * 0.3
+        q = _pack_q(W, natural); KB = (in_f + 31) // 32
+        assert q.numel() == (out_f // 16) * KB * 64 * 8 and q.dtype == torch.float32
+        words = q.view(torch.int32).reshape(out_f // 16, KB, 64, 8)
+        def halves(u):      # int32 [.., 4] -> fp16 values [.., 8]: even k-slot in the low half
+            lo16 = (u & 0xFFFF).to(torch.int16); hi16 = ((u >> 16) & 0xFFFF).to(torch.int16)
+            return torch.stack([lo16, hi16], -1).reshape(*u.shape[:-1], 8).view(torch.float16).float()
+        val = halves(words[..., :4]) + halves(words[..., 4:])                                # hi + lo
+        back = torch.zeros(out_f, 32 * KB)
+        for mb in range(out_f // 16):
+            for kb in range(KB):
+                for lane in range(64):
+                    n, g = lane & 15, lane >> 4
+                    for e in range(8):
+                        col = 32 * kb + 8 * g + e if natural else 16 * (2 * kb + (e >> 2)) + 4 * g + (e & 3)
+                        back[16 * mb + n, col] = val[mb, kb, lane, e]
+        assert (back[:, :in_f] - W).abs().max() <= 2.0 ** -21 * W.abs().max() and (back[:, in_f:] == 0).all()
+    for nobs, kp in ((64, 64), (88, 96)):
+        assert pack_mlp_params(SharedMLP(num_observations=nobs)).numel() == 2 * nobs + 4 + 256 * kp + 256 + 128 * 256 + 128 + 64 * 128 + 64 + 16 * 64 + 16
+    m = SharedMLP();
+    with torch.no_grad(): m.net[0].weight[0, 0] = 7.0e4
+    with pytest.raises(ValueError, match="fp16 range"):
+        pack_mlp_params(m)
+
+
+@pytest.mark.gpu
+def test_policy_tiles_on_the_fp16_matrix_pipe_are_fp32_accurate():
+    """Round 4: the GNN and MLP tiles compute every fp32 product as four fp16 half products on v_mfma_f32_16x16x32_f16 (operands split hi + lo).
+    Against the torch modules evaluated in float64 their error is that of an fp32 evaluation: within 4 x torch's own fp32 error + 2e-7 on 8192
+    random observations, also with weights scaled by 4 (outputs in the thousands) and observations at the scaler's clip."""
+    from locomanipulationrl_amd.policies.graph_model import GraphPolicy, gnn_forward_hip, pack_gnn_params
+    from locomanipulationrl_amd.policies.mlp_model import SharedMLP, mlp_forward_hip, pack_mlp_params
+    torch.manual_seed(0)
+    for kind in ("gnn", "mlp"):
+        for scale_w, scale_x in ((1.0, 1.0), (1.0, 5.0), (4.0, 1.0)):
+            model = (GraphPolicy() if kind == "gnn" else SharedMLP()).cuda()
+            with torch.no_grad():
+                for p in model.parameters(): p.mul_(scale_w)
+            m64 = (GraphPolicy() if kind == "gnn" else SharedMLP()).cuda().double(); m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+            obs = (torch.randn(8192, 64, device="cuda") * scale_x).clamp(-5.0, 5.0)
+            if kind == "gnn": m, v = gnn_forward_hip(obs, pack_gnn_params(model.net, model.mean_layer, model.value_layer).cuda())
+            else: m, v = mlp_forward_hip(obs, pack_mlp_params(model).cuda())
+            with torch.no_grad():
+                mr, _, vr = m64(obs.double()); m32, _, v32 = model(obs)
+            ref_err = max(float((m32.double() - mr).abs().max()), float((v32.double() - vr).abs().max()))
+            hip_err = max(float((m.double() - mr).abs().max()), float((v.double() - vr).abs().max()))
+            scale = max(1.0, float(mr.abs().max()), float(vr.abs().max()))
+            assert hip_err <= 4.0 * ref_err + 2e-7 * scale, (kind, scale_w, scale_x, hip_err, ref_err)
