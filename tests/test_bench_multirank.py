@@ -42,13 +42,16 @@ def test_rccl_collectives_run_on_this_box():
     variable the pool needs) before the driver's 8-GPU run does."""
     code = (
         "import os, torch, torch.distributed as dist\n"
-        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1')\n"
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group(backend='nccl', rank=0, world_size=1)\n"
         "x = torch.arange(2 * 48 * 4096, device='cuda', dtype=torch.float32).reshape(2, 48, 4096); out = torch.empty(2, 48, 4096, device='cuda')\n"
         "dist.all_gather_into_tensor(out, x); g = torch.ones(58649, device='cuda'); dist.all_reduce(g); dist.barrier(device_ids=[0]); torch.cuda.synchronize()\n"
         "assert torch.equal(out, x) and float(g.sum()) == 58649.0\n"
         "dist.destroy_process_group(); print('rccl ok')\n")
-    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port)); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "rccl ok" in p.stdout, p.stderr[-2000:]
