@@ -504,15 +504,11 @@ __device__ __forceinline__ constexpr int gnn_ek(int w, int e) { int c = 0; for (
 // observations of samples s0 .. s0+15, clamped to +-obs_clip first (= the values the step kernel returns).  mean may be null.
 template <int WAVE, bool LDS_OBS>
 __device__ __forceinline__ void gnn_body(const float* obs, float obs_clip, int B, int s0, const float* __restrict__ W, float* __restrict__ mean,
-                                         float* __restrict__ value, const SampleArgs& SA, float* sPQ, float* sHm, float* sLp, int lane) {
+                                         float* __restrict__ value, const SampleArgs& SA, float* sPQ, float* sHm, float* sLp, const float* sOb, int lane) {
   constexpr int NC = gnn_count(WAVE);
   const int n = lane & 15, g = lane >> 4;
-  const int sample = min(s0 + n, B - 1);
-  const float* obr = LDS_OBS ? obs + n * 64 : obs + (size_t)sample * 64;
-  const float oclip = W[OFF_OBS_CLIP];
-  // normalised observation column c of this lane's sample
-  auto ob = [&](int c) { float o = obr[c]; if (LDS_OBS) o = fminf(fmaxf(o, -obs_clip), obs_clip);
-                         float v = (o - W[OFF_OBS_MEAN + c]) * W[OFF_OBS_ISTD + c]; return fminf(fmaxf(v, -oclip), oclip); };
+  // normalised observation column c of this lane's sample: staged once per block by gnn_block (sOb[c][sample])
+  auto ob = [&](int c) { return sOb[c * GNN_SAMPLES + n]; };
 
   float wa[4][8], bias1[2][4];      // stage-1 weights of the current layer (A operand, gathered in the accumulator's k order)
   // (four consecutive k-steps of an output block are four consecutive floats of a weight row: 16-byte loads)
@@ -743,6 +739,7 @@ struct GnnSmem {
   float sPQ[2 * GNN_Q_BUF] __attribute__((aligned(16)));      // Q of the current / the next layer: [layer parity][node][sample][32 features + pad]
   float sHm[4 * 32 * GNN_SAMPLES];                  // per-wavefront node maxima for the value head
   float sLp[12 * GNN_SAMPLES];                      // per-action log-prob terms
+  float sOb[64 * GNN_SAMPLES];                      // the normalised, clipped observation tile [column][sample]
   int rot;                                          // rotation of the wavefront -> node-set map of this block (gnn_block)
 };
 // forward of samples s0 .. s0+15 by the 256 threads of a block (contains block barriers)
@@ -756,11 +753,27 @@ __device__ __forceinline__ void gnn_block(const float* obs, float obs_clip, int 
   // rotates its sets by two, pairing 112 + 96 and 80 + 96 MFMAs per stage on a SIMD instead of 112 + 112 and 128 + 128.  Any rotation is a
   // valid assignment (the result does not depend on it); the block agrees on one through LDS.
   if (t == 0) G.rot = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) * 2;      // hwreg(HW_REG_HW_ID, 0, 4) = WAVE_ID: this wavefront's slot on its SIMD
+  {
+    // The observation tile, normalised and clipped, once per block: one 16-byte load of the observation and two of the scaler per thread
+    // (16 samples x 64 columns = 256 x 4), instead of three scattered 4-byte global loads per value in every wavefront that needs it
+    const int sm = t >> 4, c0 = (t & 15) * 4, sample = min(s0 + sm, B - 1);
+    float4 o4 = LDS_OBS ? *reinterpret_cast<const float4*>(obs + sm * 64 + c0) : *reinterpret_cast<const float4*>(obs + (size_t)sample * 64 + c0);
+    static_assert(OFF_OBS_MEAN % 2 == 0 && OFF_OBS_ISTD % 2 == 0, "the scaler vectors are read as 8-byte pairs");
+    const float2 ma = *reinterpret_cast<const float2*>(W + OFF_OBS_MEAN + c0), mb = *reinterpret_cast<const float2*>(W + OFF_OBS_MEAN + c0 + 2);
+    const float2 ia = *reinterpret_cast<const float2*>(W + OFF_OBS_ISTD + c0), ib = *reinterpret_cast<const float2*>(W + OFF_OBS_ISTD + c0 + 2);
+    const float oclip = W[OFF_OBS_CLIP];
+    float o[4] = {o4.x, o4.y, o4.z, o4.w}; const float mu[4] = {ma.x, ma.y, mb.x, mb.y}, is[4] = {ia.x, ia.y, ib.x, ib.y};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (LDS_OBS) o[i] = fminf(fmaxf(o[i], -obs_clip), obs_clip);
+      G.sOb[(c0 + i) * GNN_SAMPLES + sm] = fminf(fmaxf((o[i] - mu[i]) * is[i], -oclip), oclip);
+    }
+  }
   lds_barrier();
   const int wave = ((t >> 6) + G.rot) & 3;
-  if (wave == 0) gnn_body<0, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
-  else if (wave == 1) gnn_body<1, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
-  else if (wave == 2) gnn_body<2, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
-  else gnn_body<3, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, lane);
+  if (wave == 0) gnn_body<0, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, G.sOb, lane);
+  else if (wave == 1) gnn_body<1, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, G.sOb, lane);
+  else if (wave == 2) gnn_body<2, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, G.sOb, lane);
+  else gnn_body<3, LDS_OBS>(obs, obs_clip, B, s0, W, mean, value, SA, G.sPQ, G.sHm, G.sLp, G.sOb, lane);
 }
 
