@@ -1,0 +1,9 @@
+#!/bin/bash
+# bash tools/diag/cc_seeds.sh <first seed> <last seed>: QuadrupedPoseControlCustomController, 24000 timesteps, final success rate per seed
+for seed in $(seq $1 $2); do
+  timeout -k 10 200 python tools/train_ppo.py --task QuadrupedPoseControlCustomController --timesteps 24000 --num-envs 4096 --log-every 100 --seed $seed 2>/dev/null | grep iteration | python -c "
+import sys, json
+rows=[json.loads(l) for l in sys.stdin]
+first=next((r['timesteps'] for r in rows if r['success_rate']>=0.95), None)
+d=rows[-1]; print(json.dumps({'task': 'QuadrupedPoseControlCustomController', 'seed': $seed, 'timesteps': d['timesteps'], 'success_rate': round(d['success_rate'], 4), 'first_0.95_at': first, 'mean_reward': round(d['mean_reward'], 3)}))"
+done
