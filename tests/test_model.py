@@ -4,6 +4,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import ROOT
+
 from locomanipulationrl_amd.model.robot_model import closure_g, LIMB_STRIDE, HUB_FLOATS
 
 CLASS_DEFAULT_Q = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]
@@ -130,3 +132,25 @@ def test_foot_collider_is_the_mesh_hemisphere(robot_model, vertical_model):
     for l in range(4):
         o = HUB_FLOATS + l * LIMB_STRIDE
         assert np.allclose(tb[o + 118: o + 121], robot_model.contact_off[l], atol=1e-7) and tb[o + 121] == (1.0 if l in (1, 3) else 0.0)
+
+
+def test_plate_intersection_census_geometry():
+    """tools/plate_intersection.py (how often the plate passes through bodies that have no collider here): its batched forward
+    kinematics equals RobotModel.fk, and its three flags answer the known cases of a flipped plate lowered onto the inverted robot - resting on
+    the feet: nothing; through the links but above the frame: hull and axis; inside the frame box: all three."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import plate_intersection as PI
+    from locomanipulationrl_amd.engine_config import mani_params
+    from locomanipulationrl_amd.model.robot_model import load_model
+    rm = load_model("quadruped_robot_v2"); geo = PI.Geometry(rm, "cpu"); ep = mani_params()
+    q = np.array(ep.init_q) + 0.1 * np.random.default_rng(0).standard_normal(12)
+    Rb = PI.quat_to_mat(torch.tensor([ep.fixed_base_quat])); pb = torch.tensor([ep.fixed_base_pos])
+    R, p = geo.body_poses(torch.tensor(q[None], dtype=torch.float32), Rb, pb)
+    ref = rm.fk(q, Rb[0].numpy().astype(float), pb[0].numpy().astype(float))
+    assert max(np.abs(p[k][0].numpy() - ref[k][1]).max() for k in range(rm.nb)) < 1e-6
+    st = torch.zeros(115, 3); st[13:25] = torch.tensor(ep.init_q)[:, None]; st[40:44] = torch.tensor(ep.init_plate_quat)[:, None]
+    st[39] = torch.tensor([0.14, 0.05, 0.02])                      # plate origin heights: on the feet / among the links / inside the frame
+    frame, hull, axis, rim = (x.tolist() for x in geo.flags(st, ep, slice(0, 3)))
+    assert frame == [False, False, True] and hull == [False, True, True] and axis == [False, True, True] and rim == [False, False, False]
