@@ -263,13 +263,15 @@ def main():
             ro.close()
         # other workloads of the path, same protocol (fresh U(-1,1) actions, 4096 envs), rank 0, untimed region: BASELINE config 3, config 4's
         # per-GPU block, one PD-actuator family
-        def rate_of(params, split=None, obs=64, steps=600):
-            e2 = Engine(load_model("quadruped_robot_v2"), params, N, seed=42, device=str(dev), **({} if split is None else dict(split_env=split)))
-            oo, ss = torch.empty(N, obs, device=dev), torch.empty(N, 93, device=dev)
-            for i in range(100): e2.step(pool[i % 64], None, oo, ss, roll_rew[0], roll_done[0], out_extras)
+        def rate_of(params, split=None, obs=64, steps=600, n=N):
+            e2 = Engine(load_model("quadruped_robot_v2"), params, n, seed=42, device=str(dev), **({} if split is None else dict(split_env=split)))
+            oo, ss = torch.empty(n, obs, device=dev), torch.empty(n, 93, device=dev)
+            acts = pool if n == N else torch.rand(16, n, 12, device=dev) * 2 - 1
+            rew_, done_ = (roll_rew[0], roll_done[0]) if n == N else (torch.empty(n, device=dev), torch.empty(n, dtype=roll_done.dtype, device=dev))
+            for i in range(100): e2.step(acts[i % len(acts)], None, oo, ss, rew_, done_, out_extras)
             torch.cuda.synchronize(dev); t_ = time.perf_counter()
-            for i in range(steps): e2.step(pool[i % 64], None, oo, ss, roll_rew[0], roll_done[0], out_extras)
-            torch.cuda.synchronize(dev); r_ = N * steps / (time.perf_counter() - t_)
+            for i in range(steps): e2.step(acts[i % len(acts)], None, oo, ss, rew_, done_, out_extras)
+            torch.cuda.synchronize(dev); r_ = n * steps / (time.perf_counter() - t_)
             e2.close()
             return r_
         extra_rates = {}
@@ -281,9 +283,13 @@ def main():
                 "cotrain_block_env_steps_per_s": rate_of([loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]),
                                                           mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], split=N // 2),
                 "pd_family_env_steps_per_s": rate_of([loco_cc_params()], obs=88),
+                # BASELINE config 4 whole (32 768 co-training envs, 16 384 + 16 384) on ONE GPU: two generations of 1024 wavefronts; the stand-in
+                # for the 8-GPU case while no 8-GPU node exists (there each GPU runs the 2048 + 2048 block above)
+                "config4_all_32768_envs_on_one_gpu_env_steps_per_s": rate_of([loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]),
+                                                          mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], split=16384, steps=200, n=32768),
             }
             # BASELINE config 5: the vertical co-training task, 8192 envs, the reference's GNN policy (random init, seed 42) in the loop --
-            # 48-step rollouts (GNN forward on fp32 MFMA -> sampling -> step) replayed as one hipGraph; rank 0, untimed region
+            # 48-step rollouts (GNN forward on the matrix cores, fp32 products as split fp16 -> sampling -> step) replayed as one hipGraph; rank 0, untimed region
             from locomanipulationrl_amd.lib import POLICY_GNN
             from locomanipulationrl_amd.policies.graph_model import GraphPolicy, pack_gnn_params
             from locomanipulationrl_amd.utils.config import SimConfig, load_config
@@ -319,6 +325,8 @@ def main():
                        "parallelism": f"env-sharded x{world}, all-gather(2,48,N) per 48 steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_src, "kernel": "k_step",
+                         # what plain streaming kernels reach on an MI355X of this pool (tools/microbench/stream_copy.hip; read from profiles/, not run here)
+                         "peak_measured_stream": (lambda f: json.load(open(f)) if os.path.exists(f) else None)(os.path.join(ROOT, "profiles", "r04_stream_copy.json")),
                          "kernel_ms": k_avg_ms, "kernel_ms_definition": "HIP events around the timed region on the launch stream, minus the all-gather blocks, / steps = k_step's launch "
                                                                         "period (its duration + ~3.5 us between dependent launches; rocprofv3's average duration is in profiles/)",
                          "step_period_ms": step_period_ms, "kernel_ms_single_launch_events": k_ms[len(k_ms) // 2],

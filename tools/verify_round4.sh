@@ -3,6 +3,7 @@
 OUT=gpurun_out/r4h; mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -2 $OUT/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+tools/microbench/stream_copy.bin > $OUT/stream_copy.json; cat $OUT/stream_copy.json
 python bench.py > $OUT/bench_final.json 2>/dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_protocol.json 2>/dev/null
 python tools/bench_gnn.py 2>/dev/null > $OUT/gnn_bench.json
