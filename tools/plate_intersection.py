@@ -101,6 +101,10 @@ def mani_blocks(task):
 
 def count(env, geo, actions_fn, steps):
     task = env._task; blocks = mani_blocks(task); tot = dict(env_steps=0, frame=0, hull=0, axis=0, any=0, resets=0, frame_live=0, hull_live=0, any_live=0, hull_live_at_rim=0)
+    # episode level: an episode is TOUCHED once a link hull overlaps the plate on a live step; its outcome is read when its reset flag rises
+    # (goal_reset_buf = the reference's success flag, quadruped_manipulate_plate.py:617-631)
+    epi = dict(episodes=0, touched=0, success=0, success_touched=0, steps_after_first_touch=0)
+    N = task.num_envs; touched = torch.zeros(N, dtype=torch.bool, device=geo.dev); since = torch.zeros(N, dtype=torch.int64, device=geo.dev)
     obs = env.reset()["obs"]
     for t in range(steps):
         o, rew, done, _ = env.step(actions_fn(obs)); obs = o["obs"]
@@ -111,8 +115,20 @@ def count(env, geo, actions_fn, steps):
             tot["resets"] += int(done[sl].sum())
             live = done[sl] == 0          # the step did not end the episode: an intersection here is one the task's own tests have NOT caught
             tot["frame_live"] += int((f & live).sum()); tot["hull_live"] += int((hl & live).sum()); tot["any_live"] += int(((f | hl) & live).sum()); tot["hull_live_at_rim"] += int((rim & live).sum())
+            since[sl] += touched[sl].long(); touched[sl] |= hl & live
+            ended = done[sl] != 0; good = ended & (task.goal_reset_buf[sl] != 0)
+            epi["episodes"] += int(ended.sum()); epi["touched"] += int((ended & touched[sl]).sum()); epi["success"] += int(good.sum())
+            epi["success_touched"] += int((good & touched[sl]).sum()); epi["steps_after_first_touch"] += int(since[sl][ended & touched[sl]].sum())
+            touched[sl] &= ~ended; since[sl] *= (~ended).long()
     for k in ("frame", "hull", "axis", "any", "frame_live", "hull_live", "any_live", "hull_live_at_rim"):
         tot[k + "_pct"] = round(100.0 * tot[k] / max(tot["env_steps"], 1), 4)
+    u = epi["episodes"] - epi["touched"]
+    epi.update(touched_pct=round(100.0 * epi["touched"] / max(epi["episodes"], 1), 3), success_rate_untouched=round((epi["success"] - epi["success_touched"]) / max(u, 1), 4),
+               success_rate_touched=round(epi["success_touched"] / max(epi["touched"], 1), 4), mean_steps_after_first_touch=round(epi["steps_after_first_touch"] / max(epi["touched"], 1), 2),
+               # if every touched episode that failed had succeeded instead (the most a link collider could change)
+               success_rate_all=round(epi["success"] / max(epi["episodes"], 1), 4),
+               success_rate_upper_bound_with_colliders=round((epi["success"] + epi["touched"] - epi["success_touched"]) / max(epi["episodes"], 1), 4))
+    tot["episodes"] = epi
     return tot
 
 
