@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="drive the rollout step by step from Python instead of the captured hipGraph")
     ap.add_argument("--max-lr", type=float, default=1e-2, help="diagnostic: cap of the KL-adaptive learning rate (skrl default 1e-2)")
     ap.add_argument("--min-log-std", type=float, default=None, help="diagnostic: floor of the log-std parameter (skrl clips at -20 only)")
+    ap.add_argument("--engine", action="append", default=[], metavar="KEY=VALUE", help="diagnostic: a sim.engine override of the task YAML, e.g. friction_scale=1.0")
     a = ap.parse_args()
     # LM_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("LM_DIST_BACKEND")
@@ -32,7 +33,8 @@ def main():
     rank, _, world = D.init_from_env(backend)
     torch.manual_seed(a.seed + rank)
     env = lm.make_env(a.task, num_envs=a.num_envs, seed=a.seed, rank=rank, sim_device=f"cuda:{local}", rl_device=f"cuda:{local}",
-                      **({"overrides": {"task": {"domain_randomization": {"randomize": True}}}} if a.randomize else {}))
+                      overrides={"task": {**({"domain_randomization": {"randomize": True}} if a.randomize else {}),
+                                          **({"sim": {"engine": {k: float(v) for k, v in (kv.split("=") for kv in a.engine)}}} if a.engine else {})}})
     if a.policy == "gnn":
         from locomanipulationrl_amd.policies.graph_model import GraphPolicy
         model = GraphPolicy().to(f"cuda:{local}"); hip = True
