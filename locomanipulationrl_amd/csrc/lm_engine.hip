@@ -97,6 +97,7 @@ static int fail(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s"
 
 struct lm_engine {
   int N, n_tasks, split, nblocks, num_obs, device;
+  int w2_min_envs;         // lm_step launches k_step_w2 (two wavefronts per SIMD) from this env count on; LM_W2_MIN_ENVS overrides 32769 (tests, A/B)
   uint32_t seed;
   lm_params* d_params;     // [2]
   float* d_table;
@@ -478,10 +479,14 @@ LM_DEV void integrate_free(FreeBody& F, const M3& R, float dt) {
 // drive passes but not during the contact iterations; keeping them in registers across the PGS loop spills).
 // Layout [slot][lane] as float4 -> conflict-free 16-byte accesses.
 #ifdef LM_WAVES2
-// Diagnostic A/B build (tools/ab_build.py w2=-DLM_WAVES2): k_step compiled for TWO wavefronts per SIMD.  That needs
-// <= 256 registers per lane (amdgpu_waves_per_eu(2, 2): the compiler spills the rest to scratch) and <= 20 KB of LDS per wavefront (8 blocks per CU):
-// the stash shrinks to 18 slots (the limb's last two inertia entries ride in the free half of slot 4) and the output staging (sObs, sSt: dead until
-// the task layer, when the stash is dead) lives in the stash's memory.  Only k_step's velocity-drive specialisations are meaningful in this build.
+// k_step compiled for TWO wavefronts per SIMD.  That needs <= 256 registers per lane (amdgpu_waves_per_eu(2, 2): the
+// compiler spills the rest to scratch) and <= 20 KB of LDS per wavefront (8 blocks per CU): the stash shrinks to 18 slots (the limb's last two
+// inertia entries ride in the free half of slot 4) and the output staging (sObs, sSt: dead until the task layer, when the stash is dead) lives in
+// the stash's memory.  Same arithmetic in the same order, so the same bits (tests/test_gpu_full_size.py).  The product compiles it as a SECOND
+// translation unit (lm_engine_w2.hip: k_step_w2, the locomotion specialisation only) that lm_step dispatches beyond 32 768 envs - more than two
+// generations of one-wavefront workgroups - for un-randomised velocity-drive locomotion engines: slower below (16 384 envs: 45 against 39 us),
+// even at 24 576 / 32 768, + 5-8 % from 36 864, + 9 % at 65 536, + 14 % at 131 072, + 18 % at 262 144.
+// (-DLM_WAVES2 on the whole library, tools/ab_build.py, is the A/B build of round 4: every step kernel then has this layout.)
 #define STASH_SLOTS 18
 #define LM_STEP_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
@@ -1414,12 +1419,29 @@ LM_DEV void step_body(const StepArgs& A, const lm_params* __restrict__ P, float*
   const int kind = A.kind[(env0 >= A.split) ? 1 : 0];
 #endif
 
+#ifdef LM_W2_UNIT
+#define k_step k_step_w2
+#endif
 __global__ void __launch_bounds__(64) LM_STEP_ATTR k_step(StepArgs A) {                 // velocity-drive tasks (kinds 0, 1)
   LM_STEP_SMEM(64)
   LM_STEP_PROLOGUE
+#ifdef LM_W2_UNIT
+  // locomotion only: the plate specialisation does not live in 256 registers (measured with both in this kernel: 300 against 533 M env-steps/s on
+  // the manipulation task at 65 536 envs), so manipulation and co-training engines stay on the one-wavefront kernel at every size
+  step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash);
+#else
   if (kind == 0) step_body<0, 0, 0>(A, P, sTab, sObs, sSt, sStash); else step_body<1, 0, 0>(A, P, sTab, sObs, sSt, sStash);
+#endif
   LM_STEP_EPILOGUE
 }
+#ifdef LM_W2_UNIT
+#undef k_step
+// the second translation unit (lm_engine_w2.hip) ends here: the kernel above and its launcher
+extern "C" __attribute__((visibility("hidden"))) void lm_internal_launch_step_w2(const StepArgs* A, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_step_w2, dim3(nblocks), dim3(64), 0, s, *A);
+}
+#else
+extern "C" __attribute__((visibility("hidden"))) void lm_internal_launch_step_w2(const StepArgs* A, int nblocks, hipStream_t s);      // lm_engine_w2.hip
 
 __global__ void __launch_bounds__(64) k_step_pd(StepArgs A) {              // PD-actuator families (kinds 2 ... 5)
   LM_STEP_SMEM(LM_MAX_OBS)
@@ -1904,6 +1926,7 @@ int lm_create(lm_engine** out, int n_envs, const float* table, const lm_params* 
   h->device = device;          // every buffer lives on the device current at creation; launches check it (on_device)
   h->N = n_envs; h->n_tasks = n_tasks; h->split = (n_tasks == 2) ? split_env : n_envs; h->seed = seed;
   h->nblocks = (n_envs + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE;
+  { const char* e = getenv("LM_W2_MIN_ENVS"); h->w2_min_envs = e ? atoi(e) : 32769; }
   h->num_obs = params[0].num_obs; h->dr_enabled = params[0].dr_enabled != 0;
   h->h_params[0] = params[0]; h->h_params[1] = params[n_tasks - 1];
   derive_params(&h->h_params[0]); derive_params(&h->h_params[1]);
@@ -1992,8 +2015,11 @@ int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* o
   StepArgs A = make_args(h, actions, goal_rand, out_obs, out_states, out_rew, out_resets); A.W.out_extras = out_extras;
   drop_unrequested_views(h, A);
   const bool pd = A.kind[0] >= 2;                                  // both blocks are of one actuator family (lm_create)
-  void (*kern)(StepArgs) = h->dr_enabled ? (pd ? k_step_dr_pd : k_step_dr) : (pd ? k_step_pd : k_step);
-  hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(64), 0, s, A);
+  if (!h->dr_enabled && A.kind[0] == 0 && A.kind[1] == 0 && h->N >= h->w2_min_envs) lm_internal_launch_step_w2(&A, h->nblocks, s);      // locomotion, two wavefronts per SIMD: ahead beyond 32 768 envs
+  else {
+    void (*kern)(StepArgs) = h->dr_enabled ? (pd ? k_step_dr_pd : k_step_dr) : (pd ? k_step_pd : k_step);
+    hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(64), 0, s, A);
+  }
   HIPCHK(hipGetLastError());
   return LM_OK;
 }
@@ -2122,3 +2148,4 @@ uint64_t lm_internal_args_key(const lm_engine* h) {
   return h ? ((uint64_t)h->seed | ((uint64_t)((h->view_obs ? 1 : 0) | (h->view_states ? 2 : 0) | (h->view_terms ? 4 : 0)) << 32)) : 0ull;
 }
 int lm_internal_fail(int code, const char* msg) { return fail(code, msg); }
+#endif      // !LM_W2_UNIT

@@ -119,7 +119,7 @@ def hipcc_command(extra, out):
     # -amdgpu-mfma-vgpr-form: the MFMA accumulators of the policy tiles live in ordinary VGPRs, so the VALU work on them (ELU, max aggregation,
     # LDS stores) needs no v_accvgpr_read per element (504 of them in k_gnn_forward)
     return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-            "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", *extra, os.path.join(_CSRC, "lm_engine.hip"), os.path.join(_CSRC, "lm_policy.hip"), "-o", out]
+            "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", *extra, os.path.join(_CSRC, "lm_engine.hip"), os.path.join(_CSRC, "lm_engine_w2.hip"), os.path.join(_CSRC, "lm_policy.hip"), "-o", out]
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:

@@ -145,3 +145,34 @@ def test_extras_reduction_beyond_131040_wavefronts():
         assert int(eng.stats_i64[0]) == ns and int(eng.stats_i64[1]) == nr
     assert eng.blowups == 0 and 0 < int(eng.stats_i64[1]) < 700_000      # resets were counted, and the window has rolled over
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["loco", "mani", "cotrain_ragged"])
+def test_two_wavefront_step_kernel_is_bit_identical(case, monkeypatch):
+    """Beyond 32 768 envs lm_step launches k_step_w2 on locomotion engines, the step kernel compiled for two wavefronts per SIMD
+    (csrc/lm_engine_w2.hip).  Same arithmetic in the same order: forced at a test size (LM_W2_MIN_ENVS, read by lm_create) it must
+    return the bits of k_step - outputs, extras and the whole simulator state - over 60 random-action steps with their resets.  Manipulation and
+    co-training engines stay on k_step at every size (the cases check that the switch leaves them alone)."""
+    from locomanipulationrl_amd.engine_config import loco_params, mani_params
+    from locomanipulationrl_amd.lib import Engine
+    from locomanipulationrl_amd.model.robot_model import load_model
+    rm = load_model("quadruped_robot_v2")
+    cq = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]
+    if case == "loco": N, eps, kw = 4096, [loco_params()], {}
+    elif case == "mani": N, eps, kw = 4096, [mani_params()], {}
+    else: N, eps, kw = 4090, [loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]), mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], dict(split_env=2048)
+    monkeypatch.delenv("LM_W2_MIN_ENVS", raising=False)
+    a = Engine(rm, eps, N, seed=5, **kw)
+    monkeypatch.setenv("LM_W2_MIN_ENVS", "16")
+    b = Engine(rm, eps, N, seed=5, **kw)
+    monkeypatch.delenv("LM_W2_MIN_ENVS", raising=False)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    outs = [[torch.zeros(N, 64, device="cuda"), torch.zeros(N, 93, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.int64, device="cuda"), torch.zeros(13, device="cuda")] for _ in range(2)]
+    resets = 0
+    for t in range(60):
+        act = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1
+        a.step(act, None, *outs[0]); b.step(act, None, *outs[1])
+        for x, y in zip(outs[0], outs[1]): assert torch.equal(x, y), (case, t)
+        resets += int(outs[0][3].sum())
+    assert torch.equal(a.state, b.state) and torch.equal(a.cnt, b.cnt) and resets > 0
+    a.close(); b.close()
