@@ -165,7 +165,10 @@ int lm_destroy(lm_engine* h);
  *               obs [N][lm_num_obs], states [N][93], rew [N], resets int64 [N], extras float [LM_NUM_EXTRAS]
  *   stream      hipStream_t (void* here so the header needs no HIP include)
  * With params.dr_enabled the same launch also applies the action noise (before the clamp), samples this step's physics attributes
- * and adds the observation noise (obs_buf and out_obs); the staged entry points below refuse a randomised engine. */
+ * and adds the observation noise (obs_buf and out_obs); the staged entry points below refuse a randomised engine.
+ * One kernel launch.  Un-randomised velocity-drive locomotion engines of more than 32 768 envs get the build of the same kernel for two
+ * wavefronts per SIMD (k_step_w2: same bits, faster beyond two generations of workgroups; the environment variable LM_W2_MIN_ENVS, read
+ * by lm_create, moves that threshold). */
 int lm_step(lm_engine* h, const float* actions, const float* goal_rand, float* out_obs, float* out_states,
             float* out_rew, int64_t* out_resets, float* out_extras, void* stream);
 
