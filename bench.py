@@ -285,6 +285,9 @@ def main():
                 "pd_family_env_steps_per_s": rate_of([loco_cc_params()], obs=88),
                 # BASELINE config 4 whole (32 768 co-training envs, 16 384 + 16 384) on ONE GPU: two generations of 1024 wavefronts; the stand-in
                 # for the 8-GPU case while no 8-GPU node exists (there each GPU runs the 2048 + 2048 block above)
+                # the top of the throughput curve: 131 072 locomotion envs on one GPU (beyond 32 768 envs lm_step launches the two-wavefronts-per-SIMD
+                # build of the step kernel)
+                "locomotion_131072_envs_env_steps_per_s": rate_of([loco_params()], steps=100, n=131072),
                 "config4_all_32768_envs_on_one_gpu_env_steps_per_s": rate_of([loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]),
                                                           mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], split=16384, steps=200, n=32768),
             }
