@@ -147,7 +147,7 @@ def test_extras_reduction_beyond_131040_wavefronts():
     eng.close()
 
 
-@pytest.mark.parametrize("case", ["loco", "mani", "cotrain_ragged"])
+@pytest.mark.parametrize("case", ["loco", "vertical", "mani", "cotrain_ragged"])
 def test_two_wavefront_step_kernel_is_bit_identical(case, monkeypatch):
     """Beyond 32 768 envs lm_step launches k_step_w2 on locomotion engines, the step kernel compiled for two wavefronts per SIMD
     (csrc/lm_engine_w2.hip).  Same arithmetic in the same order: forced at a test size (LM_W2_MIN_ENVS, read by lm_create) it must
@@ -159,6 +159,12 @@ def test_two_wavefront_step_kernel_is_bit_identical(case, monkeypatch):
     rm = load_model("quadruped_robot_v2")
     cq = [-1.2, 1.2, 1.2, -1.2, -1.22, -1.92, 1.92, 1.22, 1.92, 1.22, -1.22, -1.92]
     if case == "loco": N, eps, kw = 4096, [loco_params()], {}
+    elif case == "vertical":      # the other robot model (quadfinger.urdf) through the task class's own parameters
+        from locomanipulationrl_amd.utils.config import SimConfig, load_config
+        from locomanipulationrl_amd.utils.task_util import task_map
+        name = "QuadrupedPoseControlVertical"; N = 2064
+        task = task_map()[name](name=name, sim_config=SimConfig(load_config(name, num_envs=N)), env=None)
+        rm, eps, kw = load_model(task.model_asset), task.engine_params(), {}
     elif case == "mani": N, eps, kw = 4096, [mani_params()], {}
     else: N, eps, kw = 4090, [loco_params(init_q=cq, init_base_pos=[0, 0, 0.18]), mani_params(init_q=cq, fixed_base_pos=[0, 0, 0.5], init_plate_pos=[0, 0, 0.68])], dict(split_env=2048)
     monkeypatch.delenv("LM_W2_MIN_ENVS", raising=False)
