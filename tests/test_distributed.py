@@ -17,6 +17,15 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception:      # reported to the parent instead of a silent non-zero exit (the parent retries a failed rendezvous once on a fresh port)
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import locomanipulationrl_amd as lm
@@ -40,14 +49,34 @@ def _worker(rank, world, port, q):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_rollout_allgather():
+def _run_two_ranks():
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs: p.start()
-    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
-    for p in procs: p.join(60)
-    assert all(p.exitcode == 0 for p in procs)
+    try:
+        import queue
+        res = []
+        for _ in range(2):
+            try: x = q.get(timeout=240)
+            except queue.Empty: return None, "a rank did not report within 240 s"
+            if x[0] == "error": return None, x[2]      # (the other rank, blocked in the rendezvous, is terminated below)
+            res.append(x)
+        for p in procs: p.join(120)
+        if not all(p.exitcode == 0 for p in procs):
+            return None, f"exit codes {[p.exitcode for p in procs]}"
+        return sorted(res, key=lambda x: x[0]), ""
+    finally:
+        for p in procs:
+            if p.is_alive(): p.terminate()      # our own children, by handle
+
+
+def test_two_rank_sharding_and_rollout_allgather():
+    res, why = _run_two_ranks()
+    if res is None:      # the free port can be taken between its probe and the rendezvous: one retry on a fresh port
+        print("first attempt failed:", why)
+        res, why = _run_two_ranks()
+    assert res is not None, why
     (r0, s0, c0, ret0, g0, a0, ge0, e0, goal0), (r1, s1, c1, ret1, g1, a1, ge1, e1, goal1) = res
     assert (s0, c0, s1, c1) == (0, 32, 32, 32)
     assert g0.shape == (6, 64) and torch.equal(g0, g1) and torch.equal(a0, a1)           # every rank holds the global rollout
